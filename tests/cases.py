@@ -1,0 +1,86 @@
+"""Shared test-case definitions: model shapes, seeded synthetic inputs and the per-step noise
+convention.  Used by tools/make_golden.py (which runs the reference) and by the tests (which run
+the oracle and the HIP path), so that all three see identical inputs.  Input distributions follow
+SURVEY.md section 8(d)."""
+import torch
+
+MNIST_SIZES = [7840, 10, 100, 10]
+MNIST_NAMES = ["fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"]
+CIFAR_SIZES = [432, 4608, 320, 10]
+CIFAR_NAMES = ["conv1.weight", "conv2.weight", "fc.weight", "fc.bias"]
+
+CASES = {
+    # reduced-width models with the real token plans (26 tokens) and the real head dims (96 / 128)
+    "mnist_small": dict(parameter_sizes=MNIST_SIZES, parameter_names=MNIST_NAMES, n_embd=192, n_head=2,
+                        n_layer=2, chunk_size=1000, split_policy="chunk_within_layer", loss_lo=0.3, loss_hi=2.4,
+                        loss_target=0.0, w_std=0.538),
+    "cifar_small": dict(parameter_sizes=CIFAR_SIZES, parameter_names=CIFAR_NAMES, n_embd=256, n_head=2,
+                        n_layer=2, chunk_size=576, split_policy="chunk_within_layer", loss_lo=40.0, loss_hi=90.0,
+                        loss_target=35.0, w_std=0.538),
+    # the pretrained configurations (configs/train/mnist_loss.yaml:34-47, cifar10_error.yaml:34-47)
+    "mnist": dict(parameter_sizes=MNIST_SIZES, parameter_names=MNIST_NAMES, n_embd=1536, n_head=16,
+                  n_layer=12, chunk_size=1000, split_policy="chunk_within_layer", loss_lo=0.3, loss_hi=2.4,
+                  loss_target=0.0, w_std=0.538),
+    "cifar": dict(parameter_sizes=CIFAR_SIZES, parameter_names=CIFAR_NAMES, n_embd=2048, n_head=16,
+                  n_layer=12, chunk_size=576, split_policy="chunk_within_layer", loss_lo=40.0, loss_hi=90.0,
+                  loss_target=35.0, w_std=0.538),
+}
+
+
+def gpt_kwargs(case):
+    c = CASES[case]
+    return dict(parameter_sizes=list(c["parameter_sizes"]), parameter_names=list(c["parameter_names"]),
+                num_frequencies=128, max_freq_log2=14, predict_xstart=True, absolute_loss_conditioning=True,
+                n_embd=c["n_embd"], n_head=c["n_head"], n_layer=c["n_layer"], chunk_size=c["chunk_size"],
+                split_policy=c["split_policy"], encoder_depth=1, decoder_depth=1,
+                attn_pdrop=0.0, resid_pdrop=0.0, embd_pdrop=0.0)
+
+
+def make_inputs(case, B, seed):
+    """(x, t, loss_target, loss_prev, x_prev), all CPU; x/x_prev fp32 (B,D), t int64, losses fp32 (B,)."""
+    c = CASES[case]
+    D = sum(c["parameter_sizes"])
+    g = torch.Generator().manual_seed(seed)
+    x_prev = torch.randn(B, D, generator=g) * c["w_std"]
+    x = torch.randn(B, D, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    t[0] = 999
+    if B > 1:
+        t[1] = 0
+    loss_prev = c["loss_lo"] + (c["loss_hi"] - c["loss_lo"]) * torch.rand(B, generator=g)
+    loss_target = torch.full((B,), float(c["loss_target"]))
+    return x, t, loss_target, loss_prev, x_prev
+
+
+def step_noise(base_seed, i, B, D):
+    """N(0,1) noise drawn at diffusion index i (i = -1: the start noise); seed = base_seed + 1 + i."""
+    g = torch.Generator().manual_seed(base_seed + 1 + i)
+    return torch.randn(B, D, generator=g)
+
+
+def slim(a, stride=37):
+    """Same strided sampling of large tensors as tools/make_golden.py uses when storing them."""
+    import numpy as np
+    a = np.asarray(a)
+    return a.reshape(-1)[::stride].copy() if a.size > 20000 else a
+
+
+def block_case(d, seed=5):
+    """Weights and input of the full-width single-Block fixture (g4_block), in the parameter order
+    ln1.w, ln1.b, ln2.w, ln2.b, attn.{key,query,value,proj}.{w,b}, mlp.0.{w,b}, mlp.2.{w,b}."""
+    g = torch.Generator().manual_seed(seed)
+    names = ["ln1.weight", "ln1.bias", "ln2.weight", "ln2.bias"]
+    shapes = [(d,)] * 4
+    for nm in ("key", "query", "value", "proj"):
+        names += [f"attn.{nm}.weight", f"attn.{nm}.bias"]
+        shapes += [(d, d), (d,)]
+    names += ["mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias"]
+    shapes += [(4 * d, d), (4 * d,), (d, 4 * d), (d,)]
+    sd = {}
+    for n, s in zip(names, shapes):
+        if len(s) == 2:
+            sd[n] = torch.randn(s, generator=g) * 0.02
+        else:
+            sd[n] = torch.randn(s, generator=g) * 0.1 + (1.0 if n in ("ln1.weight", "ln2.weight") else 0.0)
+    xin = torch.randn(2, 26, d, generator=g)
+    return sd, xin

@@ -1,0 +1,125 @@
+"""The oracle (CPU restatement) against the golden vectors produced by the reference itself
+(tools/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import denoiser as od
+from oracle import diffusion as odf
+from oracle import permute as op
+from tests.cases import CASES, block_case, make_inputs, slim, step_noise
+
+
+def plan_of(case, predict_xstart=True):
+    c = CASES[case]
+    return od.Plan(c["parameter_sizes"], 128, 14, True, c["n_head"], c["n_embd"], c["n_layer"],
+                   c["chunk_size"], c["split_policy"], predict_xstart)
+
+
+def test_g1_splits(golden):
+    g = golden("g1_splits")
+    tasks = {"mnist": ([7840, 10, 100, 10], 1000), "cifar": ([432, 4608, 320, 10], 576)}
+    for tname, (sizes, chunk) in tasks.items():
+        nested = [sizes, sizes, [257], [257], [257], [257]]
+        for pol in ("chunk", "layer_by_layer", "chunk_within_layer", "chunk_within_input"):
+            assert od.build_splits(nested, pol, chunk) == g[f"{tname}_{pol}_in"].tolist()
+            assert od.build_splits([sizes], pol, chunk) == g[f"{tname}_{pol}_out"].tolist()
+    p = plan_of("mnist")
+    assert p.T == 26 and p.D == 7960 and len(p.output_splits) == 11
+    p = plan_of("cifar")
+    assert p.T == 26 and p.D == 5370 and len(p.output_splits) == 11
+
+
+def test_g2_freq(golden):
+    g = golden("g2_freq")
+    f = od.frequencies(128, 14)
+    assert np.array_equal(f.numpy(), g["frequencies"])
+    assert np.array_equal(od.freq_embed(torch.from_numpy(g["t"]), f).numpy(), g["t_emb"])
+    assert np.array_equal(od.freq_embed(torch.from_numpy(g["l32"]), f).numpy(), g["l32_emb"])
+    assert np.array_equal(od.freq_embed(torch.from_numpy(g["l64"]), f).numpy(), g["l64_emb"])
+    assert np.array_equal(od.freq_embed(torch.from_numpy(g["l32"]).view(-1, 1), f).numpy(), g["l32_col_emb"])
+
+
+@pytest.mark.parametrize("case", ["mnist_small", "cifar_small"])
+def test_g3_forward(golden, case):
+    g = golden(f"g3_forward_{case}")
+    plan = plan_of(case)
+    sd = od.random_state_dict(plan, seed=0)
+    chk = [float(sd["decoder.blocks.0.attn.key.weight"].double().sum()), float(sd["decoder.pos_emb"].double().sum()),
+           float(sd["decoder.output_parameter_projections.0.0.weight"].double().sum())]
+    assert np.allclose(chk, g["w_checksum"], rtol=0, atol=1e-9), "seeded weights drifted"
+    x, t, lt, lp, xp = make_inputs(case, B=4, seed=11)
+    taps = {}
+    out = od.forward(sd, plan, x, t, lt, lp, xp, taps=taps)
+    np.testing.assert_allclose(out.numpy(), g["out"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(taps["block0"].numpy(), g["block0"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(taps["ln_f"].numpy(), g["ln_f"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose((taps["embed"] - sd["decoder.pos_emb"]).numpy(), g["ln_in"], rtol=1e-5, atol=1e-5)
+    out2 = od.forward(sd, plan, x, t, lt.view(-1, 1).double(), lp.view(-1, 1).double(), xp)
+    np.testing.assert_allclose(out2.numpy(), g["out_col64"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("name,d,H", [("mnist", 1536, 16), ("cifar", 2048, 16)])
+def test_g4_block(golden, name, d, H):
+    g = golden("g4_block")
+    sd, xin = block_case(d)
+    y = od.block({"b." + k: v for k, v in sd.items()}, "b.", xin, H)
+    np.testing.assert_allclose(y.numpy(), g[f"{name}_y"], rtol=1e-5, atol=1e-5)
+
+
+def test_g5_tables(golden):
+    g = golden("g5_tables")
+    for tag, resp in (("full", ""), ("r50", "50"), ("ddim25", "ddim25")):
+        tb = odf.Tables(1000, resp)
+        assert tb.timestep_map == g[f"{tag}_timestep_map"].tolist()
+        for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+                  "sqrt_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+                  "posterior_variance", "posterior_log_variance_clipped", "posterior_mean_coef1",
+                  "posterior_mean_coef2"):
+            assert np.array_equal(getattr(tb, k), g[f"{tag}_{k}"]), (tag, k)
+    assert odf.Tables(1000).betas[0] == 9.999999999998899e-05
+
+
+@pytest.mark.parametrize("case,tag", [("mnist_small", "x0"), ("mnist_small", "eps"), ("cifar_small", "x0")])
+def test_g6_training_loss(golden, case, tag):
+    g = golden(f"g6_training_{case}_{tag}")
+    px = tag == "x0"
+    plan = plan_of(case, px)
+    sd = od.random_state_dict(plan, seed=0)
+    _, _, lt, lp, xp = make_inputs(case, B=6, seed=21)
+    tb = odf.Tables(1000)
+    x_start, t, noise = (torch.from_numpy(g[k]) for k in ("x_start", "t", "noise"))
+    params = {k: v.clone().requires_grad_(v.is_floating_point() and k != "scalar_embedder.frequencies") for k, v in sd.items()}
+    fn = lambda x, tt: od.forward(params, plan, x, tt, lt.double(), lp.double(), xp)
+    mse, out, x_t = odf.training_mse(tb, fn, x_start, t, noise, px)
+    np.testing.assert_allclose(x_t.detach().numpy(), g["x_t"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(mse.detach().numpy(), g["mse"], rtol=1e-5, atol=1e-7)
+    mse.mean().backward()
+    for k in g.files:
+        if k.startswith("grad::"):
+            np.testing.assert_allclose(slim(params[k[6:]].grad.numpy()), g[k], rtol=1e-4, atol=1e-7, err_msg=k)
+
+
+@pytest.mark.parametrize("case,resp,tag,px,clip", [
+    ("mnist_small", "", "full", True, False), ("mnist_small", "50", "r50", True, False),
+    ("cifar_small", "50", "r50", True, False), ("mnist_small", "50", "r50_eps_clip", False, True)])
+def test_g7_sampling(golden, case, resp, tag, px, clip):
+    g = golden(f"g7_sampling_{case}_{tag}")
+    plan = plan_of(case, px)
+    sd = od.random_state_dict(plan, seed=0)
+    tb = odf.Tables(1000, resp)
+    assert tb.T == int(g["num_steps"])
+    B = 3
+    _, _, lt, lp, xp = make_inputs(case, B=B, seed=31)
+    with torch.no_grad():
+        fn = lambda x, tt: od.forward(sd, plan, x, tt, lt, lp, xp)
+        final = odf.p_sample_loop(tb, fn, step_noise(1234, -1, B, plan.D), lambda i: step_noise(1234, i, B, plan.D), px, clip)
+    np.testing.assert_allclose(final.numpy(), g["sample_at_0"], rtol=1e-4, atol=1e-4)
+
+
+def test_g8_permute(golden):
+    g = golden("g8_permute")
+    for seed in range(16):
+        assert np.array_equal(op.mlp_index(*op.draw_mlp(seed)), g["mlp"][seed].astype(np.int64))
+        assert np.array_equal(op.cnn_index(*op.draw_cnn(seed)), g["cnn"][seed].astype(np.int64))
+        assert sorted(op.mlp_index(*op.draw_mlp(seed)).tolist()) == list(range(7960))
