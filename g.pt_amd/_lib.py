@@ -1,0 +1,123 @@
+"""ctypes binding of the C-ABI library (include/gpt_hip.h).  There is no CPU fallback: if the HIP
+library is missing, or a tensor is not on a GPU, the call fails loudly."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgpt_hip.so")
+
+F32, BF16 = 0, 1
+EPI_STORE, EPI_GELU, EPI_RESADD, EPI_STORE_F32, EPI_GELU_AUX, EPI_DGELU, EPI_ACCUM_F32 = range(7)
+MAX_TOKENS = 40
+SRC_X, SRC_XPREV, SRC_SCALAR = 0, 1, 2
+NCOEF = 8
+C_SQRT_AC, C_SQRT_1MAC, C_POST1, C_POST2, C_LOGVAR, C_RECIP, C_RECIPM1, C_SPARE = range(8)
+
+vp, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
+
+
+class Layer(C.Structure):
+    _fields_ = [(n, vp) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "wqkv", "bqkv", "wproj", "bproj",
+                                  "w1", "b1", "w2", "b2")]
+
+
+class Model(C.Structure):
+    _fields_ = [(n, i32) for n in ("dtype", "d", "n_head", "n_layer", "T", "D", "nfreq", "n_scalar",
+                                   "n_in_tok", "n_out_tok")] + \
+               [(n, vp) for n in ("freqs", "pos_emb", "ln_in_w", "ln_in_b", "ln_f_w", "ln_f_b")] + \
+               [("enc_w", vp * MAX_TOKENS), ("enc_w_ld", i64 * MAX_TOKENS), ("enc_k", i32 * MAX_TOKENS),
+                ("enc_src", i32 * MAX_TOKENS), ("enc_off", i32 * MAX_TOKENS),
+                ("dec_w", vp * MAX_TOKENS), ("dec_n", i32 * MAX_TOKENS), ("dec_off", i32 * MAX_TOKENS),
+                ("layers", C.POINTER(Layer))]
+
+
+class Workspace(C.Structure):
+    _fields_ = [("B_max", i32), ("layer_stride", i32)] + \
+               [(n, vp) for n in ("scal", "enc", "x", "h1", "qkv", "att", "h2", "pre", "act", "hf", "stats")]
+
+
+_PROTOS = {
+    "gpt_abi_version": ([], i32),
+    "gpt_gemm_nt": ([i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp], i32),
+    "gpt_layernorm": ([vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, f32, vp], i32),
+    "gpt_attention": ([i32, vp, vp, i32, i32, i32, i32, vp], i32),
+    "gpt_scalar_tokens": ([vp, vp, vp, i32, vp, i32, i32, vp, i32, vp], i32),
+    "gpt_encode_tokens": ([i32, i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64), C.POINTER(i32),
+                           vp, i32, i32, vp], i32),
+    "gpt_decode_tokens": ([i32, i32, vp, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), vp, vp, i32, i32, i32,
+                           vp], i32),
+    "gpt_q_sample": ([vp, vp, vp, vp, vp, i32, i32, vp], i32),
+    "gpt_posterior_step": ([vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, i32, i32, vp], i32),
+    "gpt_mse_rows": ([vp, vp, vp, i32, i32, vp], i32),
+    "gpt_mse_rows_bwd": ([vp, vp, vp, vp, i32, i32, vp], i32),
+    "gpt_randn": ([vp, i64, u64, u64, vp], i32),
+    "gpt_fill_i64": ([vp, i64, i64, vp], i32),
+    "gpt_f32_to_bf16": ([vp, vp, i64, vp], i32),
+    "gpt_bf16_to_f32": ([vp, vp, i64, vp], i32),
+    "gpt_transpose": ([i32, vp, vp, i32, i32, vp], i32),
+    "gpt_perm_index_mlp": ([vp, vp, i32, i32, i32, i32, vp], i32),
+    "gpt_perm_index_cnn": ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    "gpt_perm_gather": ([C.POINTER(vp), C.POINTER(vp), i32, vp, i32, i32, vp], i32),
+    "gpt_denoiser_forward": ([C.POINTER(Model), C.POINTER(Workspace), vp, vp, vp, vp, i32, vp, vp, i32, vp], i32),
+    "gpt_sample_loop": ([C.POINTER(Model), C.POINTER(Workspace), vp, vp, vp, i32, vp, vp, C.POINTER(i64), i32, i32,
+                         i32, i32, i32, f32, f32, vp, u64, vp, vp, vp, vp, i32, vp], i32),
+}
+
+_lib = None
+
+
+class GptHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library.  Raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GptHipError(f"{LIB_PATH} is missing: build it with `make -C g.pt_amd/csrc` "
+                              "(there is no CPU fallback for the HIP path)")
+        L = C.CDLL(LIB_PATH)
+        L.gpt_last_error.restype = C.c_char_p
+        L.gpt_last_error.argtypes = []
+        for name, (args, res) in _PROTOS.items():
+            fn = getattr(L, name)          # AttributeError here = the .so does not export what the header declares
+            fn.argtypes, fn.restype = args, res
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return ["gpt_last_error"] + list(_PROTOS)
+
+
+def check(status, what):
+    if status != 0:
+        raise GptHipError(f"{what} failed (status {status}): {lib().gpt_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a GPU tensor (None -> NULL).  CPU tensors are refused: no silent fallback."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise GptHipError("the HIP path needs GPU tensors (got a CPU tensor); there is no CPU fallback")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(dtype):
+    if dtype in (torch.float32, "fp32", "f32", F32):
+        return F32
+    if dtype in (torch.bfloat16, "bf16", BF16):
+        return BF16
+    raise ValueError(f"unsupported compute dtype {dtype!r} (fp32 or bf16)")
+
+
+def torch_dtype(code):
+    return torch.bfloat16 if code == BF16 else torch.float32

@@ -1,0 +1,166 @@
+// Short-sequence fused multi-head attention for gfx950 (T <= 32 tokens, no mask, dropout 0).
+// Replaces Gpt/models/transformer.py:43-47:  softmax(q k^T / sqrt(hd)) v  per (batch, head).
+//
+// One wavefront owns one (batch, head).  T is padded to the 32-row MFMA tile.
+//   S^T = K . Q^T        MFMA with K as the A operand and Q as the B operand, so the accumulator holds, per
+//                        lane, ONE query column (lane & 31) and 16 of the 32 key rows in its registers:
+//                        key(reg, half) = (reg & 3) + 8 * (reg >> 2) + 4 * half.
+//   softmax over keys    = over the lane's 16 registers plus one exchange with lane ^ 32 (wavefront
+//                        reduction, no LDS);
+//   O^T = V^T . P^T      the softmaxed accumulator IS the B operand of the second MFMA (a product that sums
+//                        over the accumulator's row index needs no lane movement); V^T fragments are read
+//                        with the matching key order.
+// fp32: v_mfma_f32_32x32x2_f32 (exact).  bf16: v_mfma_f32_32x32x16_bf16, P rounded to bf16 once.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int key_of(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ y, int B, int Ttok,
+                                                        int n_head) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 31, hh = lane >> 5;
+  const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= B * n_head) return;
+  const int b = pair / n_head, h = pair % n_head;
+  const int d = n_head * HD;
+  const int64_t ld = 3 * (int64_t)d;
+  const T* qb = qkv + (int64_t)b * Ttok * ld + h * HD;
+  const T* kb = qb + d;
+  const T* vb = qb + 2 * d;
+  const bool rvalid = r < Ttok;
+  const int64_t roff = (int64_t)(rvalid ? r : 0) * ld;
+
+  f32x16 S;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) S[e] = 0.f;
+
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) {
+      u32x4 a = *reinterpret_cast<const u32x4*>(kb + roff + ks * 16 + hh * 8);
+      u32x4 q = *reinterpret_cast<const u32x4*>(qb + roff + ks * 16 + hh * 8);
+      if (!rvalid) { a = u32x4{0, 0, 0, 0}; q = u32x4{0, 0, 0, 0}; }
+      S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, q), S, 0, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < HD / 8; ++ks) {
+      float4 a = *reinterpret_cast<const float4*>(kb + roff + ks * 8 + hh * 4);
+      float4 q = *reinterpret_cast<const float4*>(qb + roff + ks * 8 + hh * 4);
+      if (!rvalid) { a = make_float4(0, 0, 0, 0); q = make_float4(0, 0, 0, 0); }
+      S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q.x, S, 0, 0, 0);
+      S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, q.y, S, 0, 0, 0);
+      S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, q.z, S, 0, 0, 0);
+      S = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, q.w, S, 0, 0, 0);
+    }
+  }
+
+  // softmax over keys for query column r
+  const float scale = 1.0f / sqrtf((float)HD);
+  float m = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const bool kvalid = key_of(e, hh) < Ttok;
+    S[e] = kvalid ? S[e] * scale : -INFINITY;
+    m = fmaxf(m, S[e]);
+  }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    S[e] = expf(S[e] - m);
+    sum += S[e];
+  }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) S[e] *= inv;
+
+  // O^T tiles: 32 head-dims each
+  constexpr int ND = HD / 32;
+  f32x16 O[ND];
+#pragma unroll
+  for (int t = 0; t < ND; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) O[t][e] = 0.f;
+
+  if constexpr (sizeof(T) == 2) {
+    bf16x8 p[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) p[s][j] = (short)f32_to_bf16(S[8 * s + j]);
+#pragma unroll
+    for (int t = 0; t < ND; ++t) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int key = key_of(8 * s + j, hh);
+          v[j] = key < Ttok ? (short)vb[(int64_t)key * ld + t * 32 + r] : (short)0;
+        }
+        O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v, p[s], O[t], 0, 0, 0);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < ND; ++t) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = key_of(e, hh);
+        const float v = key < Ttok ? vb[(int64_t)key * ld + t * 32 + r] : 0.f;
+        O[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, S[e], O[t], 0, 0, 0);
+      }
+    }
+  }
+
+  // O^T[dd][query r]: registers 4g..4g+3 are 4 consecutive head-dims -> one 8/16-byte store per group
+  if (rvalid) {
+    T* yr = y + ((int64_t)b * Ttok + r) * d + h * HD;
+#pragma unroll
+    for (int t = 0; t < ND; ++t) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dd = t * 32 + 8 * g + 4 * hh;
+        if constexpr (sizeof(T) == 2) {
+          uint2 o;
+          o.x = pack_bf16x2(O[t][4 * g + 0], O[t][4 * g + 1]);
+          o.y = pack_bf16x2(O[t][4 * g + 2], O[t][4 * g + 3]);
+          *reinterpret_cast<uint2*>(yr + dd) = o;
+        } else {
+          *reinterpret_cast<float4*>(yr + dd) = make_float4(O[t][4 * g + 0], O[t][4 * g + 1], O[t][4 * g + 2], O[t][4 * g + 3]);
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+int launch(const void* qkv, void* y, int B, int T_, int n_head, int hd, hipStream_t s) {
+  const dim3 grid((B * n_head + 3) / 4), block(256);
+#define ATT(HD) hipLaunchKernelGGL((attention_kernel<T, HD>), grid, block, 0, s, (const T*)qkv, (T*)y, B, T_, n_head)
+  switch (hd) {
+    case 32: ATT(32); break;
+    case 64: ATT(64); break;
+    case 96: ATT(96); break;
+    case 128: ATT(128); break;
+    default: gpt_set_error("gpt_attention: unsupported head dim %d", hd); return -1;
+  }
+#undef ATT
+  return gpt_launch_status("gpt_attention");
+}
+
+}  // namespace
+
+extern "C" int gpt_attention(int dtype, const void* qkv, void* y, int B, int T, int n_head, int hd, void* stream) {
+  GPT_REQUIRE(dtype == GPT_F32 || dtype == GPT_BF16, "gpt_attention: bad dtype %d", dtype);
+  GPT_REQUIRE(qkv && y, "gpt_attention: null operand");
+  GPT_REQUIRE(B > 0 && T > 0 && T <= 32 && n_head > 0, "gpt_attention: need 0 < T <= 32 (B=%d T=%d H=%d)", B, T, n_head);
+  GPT_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)y % 16) == 0, "gpt_attention: operands must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  return dtype == GPT_BF16 ? launch<bf16_t>(qkv, y, B, T, n_head, hd, s) : launch<float>(qkv, y, B, T, n_head, hd, s);
+}

@@ -1,0 +1,80 @@
+// Shared device/host helpers for the gfx950 G.pt kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/gpt_hip.h"
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;  // one 32x32x16 / 16x16x32 bf16 MFMA operand
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+void gpt_set_error(const char* fmt, ...);
+
+#define GPT_REQUIRE(cond, ...)          \
+  do {                                  \
+    if (!(cond)) {                      \
+      gpt_set_error(__VA_ARGS__);       \
+      return -1;                        \
+    }                                   \
+  } while (0)
+
+static inline int gpt_launch_status(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    gpt_set_error("%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even; NaN stays NaN (quiet)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+template <typename T>
+struct elem;
+template <>
+struct elem<float> {
+  __device__ static __forceinline__ float load(const float* p) { return *p; }
+  __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <>
+struct elem<bf16_t> {
+  __device__ static __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
+  __device__ static __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact-erf GELU, as nn.GELU() (Gpt/models/transformer.py:64)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}

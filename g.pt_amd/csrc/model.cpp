@@ -1,0 +1,114 @@
+// Whole-path host drivers: one call launches every kernel of a denoiser forward, or of the whole
+// reverse-diffusion loop, on the caller's stream.  No allocation, no synchronisation, graph-capturable.
+//   Gpt.forward                     Gpt/models/transformer.py:440-464 (+ GPT.forward :302-314, Block :69-72)
+//   p_sample_loop_progressive       Gpt/diffusion/gaussian_diffusion.py:458-505
+#include "common.h"
+
+#define CHECK(call)             \
+  do {                          \
+    int _st = (call);           \
+    if (_st != 0) return _st;   \
+  } while (0)
+
+static inline size_t esize(int dtype) { return dtype == GPT_BF16 ? 2 : 4; }
+
+static int validate(const gpt_model_t* m, const gpt_workspace_t* ws, int B, const char* who) {
+  GPT_REQUIRE(m && ws, "%s: null model/workspace", who);
+  GPT_REQUIRE(m->dtype == GPT_F32 || m->dtype == GPT_BF16, "%s: bad dtype %d", who, m->dtype);
+  GPT_REQUIRE(B > 0 && B <= ws->B_max, "%s: batch %d exceeds workspace capacity %d", who, B, ws->B_max);
+  GPT_REQUIRE(m->n_in_tok == m->T && m->T <= 32 && m->T <= GPT_MAX_TOKENS, "%s: %d tokens unsupported (max 32)", who, m->T);
+  GPT_REQUIRE(m->n_out_tok > 0 && m->n_out_tok <= m->T, "%s: bad n_out_tok", who);
+  GPT_REQUIRE(m->d % m->n_head == 0, "%s: n_embd %% n_head != 0", who);
+  const int hd = m->d / m->n_head;
+  GPT_REQUIRE(hd % 32 == 0 && hd <= 128, "%s: head dim %d unsupported (multiple of 32, <= 128)", who, hd);
+  GPT_REQUIRE(m->d % 64 == 0, "%s: n_embd must be a multiple of 64", who);
+  GPT_REQUIRE(m->layers && m->n_layer > 0, "%s: no layers", who);
+  GPT_REQUIRE(!ws->layer_stride || (ws->pre && ws->stats), "%s: training workspace needs pre/stats", who);
+  return 0;
+}
+
+extern "C" int gpt_denoiser_forward(const gpt_model_t* m, const gpt_workspace_t* ws, const float* x, const int64_t* t,
+                                    const void* loss_target, const void* loss_prev, int loss_is_f64,
+                                    const float* x_prev, float* out, int B, void* stream) {
+  CHECK(validate(m, ws, B, "gpt_denoiser_forward"));
+  GPT_REQUIRE(x && t && loss_target && loss_prev && x_prev && out, "gpt_denoiser_forward: null operand");
+  const int d = m->d, T = m->T, M = B * T, L = m->n_layer, dt = m->dtype;
+  const size_t es = esize(dt);
+  const int W = 2 * m->nfreq + 1;
+  const bool keep = ws->layer_stride != 0;
+  const size_t Mmax = (size_t)ws->B_max * T;
+
+  CHECK(gpt_scalar_tokens(t, loss_target, loss_prev, loss_is_f64, m->freqs, m->nfreq, m->n_scalar, ws->scal, B, stream));
+
+  const float* src[GPT_MAX_TOKENS];
+  int64_t src_ld[GPT_MAX_TOKENS];
+  for (int i = 0; i < m->T; ++i) {
+    switch (m->enc_src[i]) {
+      case GPT_SRC_X: src[i] = x + m->enc_off[i]; src_ld[i] = m->D; break;
+      case GPT_SRC_XPREV: src[i] = x_prev + m->enc_off[i]; src_ld[i] = m->D; break;
+      case GPT_SRC_SCALAR: src[i] = ws->scal + m->enc_off[i]; src_ld[i] = (int64_t)m->n_scalar * W; break;
+      default: gpt_set_error("gpt_denoiser_forward: token %d: bad source kind %d", i, m->enc_src[i]); return -1;
+    }
+  }
+  CHECK(gpt_encode_tokens(dt, T, src, src_ld, m->enc_w, m->enc_w_ld, m->enc_k, ws->enc, B, d, stream));
+
+  auto xbuf = [&](int idx) { return ws->x + (keep ? (size_t)idx * Mmax * d : 0); };
+  auto lay = [&](void* base, int l, size_t width) {
+    return (void*)((char*)base + (keep ? (size_t)l * Mmax * width * es : 0));
+  };
+  auto stat = [&](int idx, int which) { return keep ? ws->stats + ((size_t)idx * 2 + which) * Mmax : (float*)nullptr; };
+
+  // ln_in + position embedding (transformer.py:226, 308-309)
+  CHECK(gpt_layernorm(ws->enc, m->ln_in_w, m->ln_in_b, m->pos_emb, T, xbuf(0), GPT_F32, stat(0, 0), stat(0, 1), M, d, 1e-5f, stream));
+
+  for (int l = 0; l < L; ++l) {
+    const gpt_layer_t& ly = m->layers[l];
+    float* xin = xbuf(2 * l);
+    float* xmid = xbuf(2 * l + 1);
+    float* xout = xbuf(2 * l + 2);
+    void* h1 = lay(ws->h1, l, d);
+    void* qkv = lay(ws->qkv, l, 3 * (size_t)d);
+    void* att = lay(ws->att, l, d);
+    void* h2 = lay(ws->h2, l, d);
+    void* act = lay(ws->act, l, 4 * (size_t)d);
+    CHECK(gpt_layernorm(xin, ly.ln1_w, ly.ln1_b, nullptr, 0, h1, dt, stat(1 + 2 * l, 0), stat(1 + 2 * l, 1), M, d, 1e-5f, stream));
+    CHECK(gpt_gemm_nt(dt, h1, d, ly.wqkv, d, ly.bqkv, qkv, 3 * d, nullptr, 0, M, 3 * d, d, GPT_EPI_STORE, stream));
+    CHECK(gpt_attention(dt, qkv, att, B, T, m->n_head, d / m->n_head, stream));
+    CHECK(gpt_gemm_nt(dt, att, d, ly.wproj, d, ly.bproj, xmid, d, keep ? xin : nullptr, d, M, d, d, GPT_EPI_RESADD, stream));
+    CHECK(gpt_layernorm(xmid, ly.ln2_w, ly.ln2_b, nullptr, 0, h2, dt, stat(2 + 2 * l, 0), stat(2 + 2 * l, 1), M, d, 1e-5f, stream));
+    if (keep) {
+      void* pre = lay(ws->pre, l, 4 * (size_t)d);
+      CHECK(gpt_gemm_nt(dt, h2, d, ly.w1, d, ly.b1, act, 4 * d, pre, 4 * d, M, 4 * d, d, GPT_EPI_GELU_AUX, stream));
+    } else {
+      CHECK(gpt_gemm_nt(dt, h2, d, ly.w1, d, ly.b1, act, 4 * d, nullptr, 0, M, 4 * d, d, GPT_EPI_GELU, stream));
+    }
+    CHECK(gpt_gemm_nt(dt, act, 4 * d, ly.w2, 4 * d, ly.b2, xout, d, keep ? xmid : nullptr, d, M, d, 4 * d, GPT_EPI_RESADD, stream));
+  }
+  CHECK(gpt_layernorm(xbuf(2 * L), m->ln_f_w, m->ln_f_b, nullptr, 0, ws->hf, dt, stat(2 * L + 1, 0), stat(2 * L + 1, 1), M, d, 1e-5f, stream));
+  CHECK(gpt_decode_tokens(dt, m->n_out_tok, ws->hf, T, m->dec_w, m->dec_n, m->dec_off, x_prev, out, B, d, m->D, stream));
+  return 0;
+}
+
+extern "C" int gpt_sample_loop(const gpt_model_t* m, const gpt_workspace_t* ws, float* x, const void* loss_target,
+                               const void* loss_prev, int loss_is_f64, const float* x_prev, const float* coef,
+                               const int64_t* host_timestep_map, int n_steps, int first_step, int last_step,
+                               int predict_xstart, int use_clamp, float lo, float hi, const float* noise, uint64_t seed,
+                               int64_t* t_model, int64_t* t_index, float* model_out, float* noise_buf, int B,
+                               void* stream) {
+  CHECK(validate(m, ws, B, "gpt_sample_loop"));
+  GPT_REQUIRE(x && coef && host_timestep_map && t_model && t_index && model_out, "gpt_sample_loop: null operand");
+  GPT_REQUIRE(noise || noise_buf, "gpt_sample_loop: need injected noise or a noise scratch buffer");
+  GPT_REQUIRE(n_steps > 0 && first_step < n_steps && last_step >= 0 && first_step >= last_step,
+              "gpt_sample_loop: bad step range [%d..%d] of %d", first_step, last_step, n_steps);
+  GPT_REQUIRE(ws->layer_stride == 0, "gpt_sample_loop: needs an inference workspace");
+  const int64_t BD = (int64_t)B * m->D;
+  for (int i = first_step; i >= last_step; --i) {
+    CHECK(gpt_fill_i64(t_index, B, i, stream));
+    CHECK(gpt_fill_i64(t_model, B, host_timestep_map[i], stream));
+    CHECK(gpt_denoiser_forward(m, ws, x, t_model, loss_target, loss_prev, loss_is_f64, x_prev, model_out, B, stream));
+    const float* nz = noise ? noise + (int64_t)i * BD : noise_buf;
+    if (!noise) CHECK(gpt_randn(noise_buf, BD, seed, (uint64_t)i, stream));
+    CHECK(gpt_posterior_step(model_out, x, nz, t_index, coef, predict_xstart, use_clamp, lo, hi, x, nullptr, B, m->D, stream));
+  }
+  return 0;
+}

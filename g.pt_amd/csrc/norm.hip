@@ -1,0 +1,120 @@
+// Fused LayerNorm for the residual stream (fp32 in, fp32 or bf16 out), one wavefront per row.
+// HBM-bound: algorithmic bytes per row = 4*d read + sizeof(out)*d written.
+// Replaces nn.LayerNorm at Gpt/models/transformer.py:70-71 (ln1/ln2), :226 (ln_in, with the
+// position-embedding add of :308-309 folded in through `add`), :311 (ln_f).
+#include "common.h"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 4;
+
+// NV = float4 per lane held in registers (d == NV * 256); NV == 0: generic d % 4 == 0, re-reads the row.
+template <int NV, typename OutT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ add,
+                                                        int add_rows, OutT* __restrict__ y, float* __restrict__ mean_out,
+                                                        float* __restrict__ rstd_out, int rows, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * d);
+  const int nv = d >> 2;
+  float4 v[NV > 0 ? NV : 1];
+  float s = 0.f;
+  if constexpr (NV > 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      v[i] = xr[lane + i * 64];
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  } else {
+    for (int c = lane; c < nv; c += 64) {
+      const float4 t = xr[c];
+      s += (t.x + t.y) + (t.z + t.w);
+    }
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+  if constexpr (NV > 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+      q += (a * a + b * b) + (c * c + e * e);
+    }
+  } else {
+    for (int c = lane; c < nv; c += 64) {
+      const float4 t = xr[c];
+      const float a = t.x - mean, b = t.y - mean, cc = t.z - mean, e = t.w - mean;
+      q += (a * a + b * b) + (cc * cc + e * e);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+  const float4* a4 = add ? reinterpret_cast<const float4*>(add + (int64_t)(row % add_rows) * d) : nullptr;
+  OutT* yr = y + (int64_t)row * d;
+  auto emit = [&](int c, const float4& t) {
+    const float4 g = g4[c], b = b4[c];
+    float4 o;
+    o.x = (t.x - mean) * rstd * g.x + b.x;
+    o.y = (t.y - mean) * rstd * g.y + b.y;
+    o.z = (t.z - mean) * rstd * g.z + b.z;
+    o.w = (t.w - mean) * rstd * g.w + b.w;
+    if (a4) {
+      const float4 a = a4[c];
+      o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    }
+    if constexpr (sizeof(OutT) == 4) {
+      reinterpret_cast<float4*>(yr)[c] = o;
+    } else {
+      uint2 p;
+      p.x = pack_bf16x2(o.x, o.y);
+      p.y = pack_bf16x2(o.z, o.w);
+      reinterpret_cast<uint2*>(yr)[c] = p;
+    }
+  };
+  if constexpr (NV > 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) emit(lane + i * 64, v[i]);
+  } else {
+    for (int c = lane; c < nv; c += 64) emit(c, xr[c]);
+  }
+}
+
+template <typename OutT>
+int launch(const float* x, const float* gamma, const float* beta, const float* add, int add_rows, void* y,
+           float* mean, float* rstd, int rows, int d, float eps, hipStream_t s) {
+  const dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(256);
+#define LN_LAUNCH(NV)                                                                                          \
+  hipLaunchKernelGGL((layernorm_kernel<NV, OutT>), grid, block, 0, s, x, gamma, beta, add, add_rows, (OutT*)y, \
+                     mean, rstd, rows, d, eps)
+  if (d == 1536) LN_LAUNCH(6);
+  else if (d == 2048) LN_LAUNCH(8);
+  else if (d == 1024) LN_LAUNCH(4);
+  else if (d == 768) LN_LAUNCH(3);
+  else if (d == 3072) LN_LAUNCH(12);
+  else LN_LAUNCH(0);
+#undef LN_LAUNCH
+  return gpt_launch_status("gpt_layernorm");
+}
+
+}  // namespace
+
+extern "C" int gpt_layernorm(const float* x, const float* gamma, const float* beta, const float* add, int add_rows,
+                             void* y, int out_dtype, float* mean, float* rstd, int rows, int d, float eps,
+                             void* stream) {
+  GPT_REQUIRE(x && gamma && beta && y, "gpt_layernorm: null operand");
+  GPT_REQUIRE(rows > 0 && d > 0 && d % 4 == 0, "gpt_layernorm: need rows > 0 and d %% 4 == 0 (rows=%d d=%d)", rows, d);
+  GPT_REQUIRE(out_dtype == GPT_F32 || out_dtype == GPT_BF16, "gpt_layernorm: bad out_dtype %d", out_dtype);
+  GPT_REQUIRE(!add || add_rows > 0, "gpt_layernorm: add needs add_rows > 0");
+  GPT_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 8) == 0 && ((uintptr_t)gamma % 16) == 0 &&
+                  ((uintptr_t)beta % 16) == 0 && ((uintptr_t)add % 16) == 0,
+              "gpt_layernorm: operands must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  if (out_dtype == GPT_F32) return launch<float>(x, gamma, beta, add, add_rows, y, mean, rstd, rows, d, eps, s);
+  return launch<bf16_t>(x, gamma, beta, add, add_rows, y, mean, rstd, rows, d, eps, s);
+}

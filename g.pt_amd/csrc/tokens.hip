@@ -1,0 +1,284 @@
+// Token-side kernels of the G.pt denoiser: frequency embedding of the scalar inputs, the ragged
+// per-token encoder Linears and the ragged per-token decoder Linears (+ global residual).
+//   FrequencyEmbedder.forward / Gpt.embed_loss   Gpt/models/transformer.py:324-334, 427-438
+//   GPT.encode_parameters                        :215-228   (26 Linears, K in {10..1000}, M = batch)
+//   GPT.decode_parameters + global residual      :230-242, 462-463
+// The encoder reads its four sources (x, x_prev, scalar tokens) in place, so the (B, 16948)
+// concatenation of :458-459 is never materialised.
+#include "common.h"
+
+// The reference rounds every product and sum separately (separate ATen kernels); hipcc contracts a*b+c into an
+// FMA by default, __fmul_rn/__fadd_rn included, which changes last bits.  Keep IEEE op-by-op rounding in this file.
+#pragma clang fp contract(off)
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ scalar tokens
+// One thread per output element.  The product f * s is formed in fp32 with one rounding and fed to the
+// full-range sinf/cosf (arguments reach 1.6e7 rad, where one fp32 ulp is a full radian).
+__global__ void scalar_tokens_kernel(const int64_t* __restrict__ t, const void* __restrict__ lt,
+                                     const void* __restrict__ lp, int is_f64, const float* __restrict__ freqs,
+                                     int nfreq, int n_scalar, float* __restrict__ out, int B) {
+  const int W = 2 * nfreq + 1;
+  const int64_t total = (int64_t)B * n_scalar * W;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int f = (int)(idx % W);
+  const int j = (int)((idx / W) % n_scalar);
+  const int b = (int)(idx / ((int64_t)W * n_scalar));
+  float s;
+  if (j == 0) {
+    s = (float)t[b];
+  } else if (is_f64) {
+    const double a = ((const double*)lt)[b], c = ((const double*)lp)[b];
+    s = j == 1 ? (float)(a - c) : (j == 2 ? (float)a : (float)c);
+  } else {
+    const float a = ((const float*)lt)[b], c = ((const float*)lp)[b];
+    s = j == 1 ? a - c : (j == 2 ? a : c);
+  }
+  float v;
+  if (f < nfreq) {
+    float arg = freqs[f] * s;
+    asm volatile("" : "+v"(arg));   // the rounded product is the argument: nothing may be fused into sinf's reduction
+    v = sinf(arg);
+  } else if (f < 2 * nfreq) {
+    float arg = freqs[f - nfreq] * s;
+    asm volatile("" : "+v"(arg));
+    v = cosf(arg);
+  } else {
+    v = s;
+  }
+  out[idx] = v;
+}
+
+// ------------------------------------------------------------------------------------------ ragged GEMMs
+// Workgroup tile: 64 batch rows x 128 output columns of ONE token; 4 waves as 2 x 2, each 32 x 64
+// (1 x 2 MFMA 32x32 tiles).  K is walked in chunks of 32 elements through a single LDS buffer; ragged K
+// (10, 100, 257, 840, 1000 ...) is zero-filled in LDS, never in memory on the activation side.
+constexpr int MAX_TOK = 40;
+constexpr int TB = 64, TN = 128, KC = 32;
+
+struct EncTok {
+  const float* src;   // fp32 [B, >=k], row stride src_ld
+  const void* w;      // T [d, w_ld], zero padded to a multiple of KC
+  int64_t src_ld, w_ld;
+  int k;
+};
+struct EncArgs {
+  EncTok tok[MAX_TOK];
+  float* out;         // fp32 [B, n_tok, d]
+  int n_tok, B, d;
+};
+
+struct DecTok {
+  const void* w;      // T [n, d]
+  int n, off;
+};
+struct DecArgs {
+  DecTok tok[MAX_TOK];
+  const void* feat;   // T [B, T, d]
+  const float* resid; // fp32 [B, D] or null
+  float* out;         // fp32 [B, D]
+  int n_tok, T, B, d, D;
+};
+
+template <typename T>
+struct Pitch {
+  static constexpr int value = KC * sizeof(T) + 16;  // bytes per LDS row: 80 (bf16) / 144 (fp32): odd number of 16-B slots
+};
+
+template <typename T>
+__device__ __forceinline__ void mma_chunk(const char* ldsA, const char* ldsW, int wr, int wc, int lane, f32x16 (&acc)[2]) {
+  constexpr int P = Pitch<T>::value;
+  const int r = lane & 31, hh = lane >> 5;
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(ldsA + (wr * 32 + r) * P + (s * 16 + hh * 8) * 2);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(ldsW + (wc * 64 + j * 32 + r) * P + (s * 16 + hh * 8) * 2);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 a = *reinterpret_cast<const float4*>(ldsA + (wr * 32 + r) * P + (q * 8 + hh * 4) * 4);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float4 b = *reinterpret_cast<const float4*>(ldsW + (wc * 64 + j * 32 + r) * P + (q * 8 + hh * 4) * 4);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[j], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// stage a [128 rows x KC] weight chunk (T, 16-byte aligned rows); rows >= nrows are clamped (dropped at store)
+template <typename T>
+__device__ __forceinline__ void stage_w(const T* w, int64_t ld, int row0, int nrows, int k0, char* lds, int tid) {
+  constexpr int P = Pitch<T>::value;
+  constexpr int V = KC * sizeof(T) / 16;           // 16-byte vectors per row: 4 (bf16) / 8 (fp32)
+  for (int i = tid; i < TN * V; i += 256) {
+    const int row = i / V, c = i % V;
+    int gr = row0 + row;
+    gr = gr < nrows ? gr : nrows - 1;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(w + (int64_t)gr * ld + k0) + c * 16);
+    *reinterpret_cast<u32x4*>(lds + row * P + c * 16) = v;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void encode_kernel(EncArgs g) {
+  constexpr int P = Pitch<T>::value;
+  __shared__ __attribute__((aligned(16))) char smem[(TB + TN) * P];
+  char* ldsA = smem;
+  char* ldsW = smem + TB * P;
+  const EncTok tk = g.tok[blockIdx.z];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int b0 = blockIdx.y * TB, n0 = blockIdx.x * TN;
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+  const int arow = tid >> 2, acol = (tid & 3) * 8;   // 64 rows x 4 threads x 8 consecutive k
+  const int gb = b0 + arow;
+  const float* srow = tk.src + (int64_t)(gb < g.B ? gb : g.B - 1) * tk.src_ld;
+  for (int k0 = 0; k0 < tk.k; k0 += KC) {
+    T* dst = reinterpret_cast<T*>(ldsA + arow * P) + acol;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = k0 + acol + e;
+      const float v = k < tk.k ? srow[k] : 0.f;
+      elem<T>::store(dst + e, v);
+    }
+    stage_w<T>((const T*)tk.w, tk.w_ld, n0, g.d, k0, ldsW, tid);
+    __syncthreads();
+    mma_chunk<T>(ldsA, ldsW, wr, wc, lane, acc);
+    __syncthreads();
+  }
+  const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wc * 64 + j * 32 + r;
+    if (n >= g.d) continue;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int b = b0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+      if (b < g.B) g.out[((int64_t)b * g.n_tok + blockIdx.z) * g.d + n] = acc[j][e];
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void decode_kernel(DecArgs g) {
+  constexpr int P = Pitch<T>::value;
+  __shared__ __attribute__((aligned(16))) char smem[(TB + TN) * P];
+  char* ldsA = smem;
+  char* ldsW = smem + TB * P;
+  const DecTok tk = g.tok[blockIdx.z];
+  const int n0 = blockIdx.x * TN;
+  if (n0 >= tk.n) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int b0 = blockIdx.y * TB;
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+  constexpr int V = KC * sizeof(T) / 16;
+  const T* feat = (const T*)g.feat;
+  for (int k0 = 0; k0 < g.d; k0 += KC) {
+    for (int i = tid; i < TB * V; i += 256) {
+      const int row = i / V, c = i % V;
+      int gb = b0 + row;
+      gb = gb < g.B ? gb : g.B - 1;
+      const char* src = reinterpret_cast<const char*>(feat + ((int64_t)gb * g.T + blockIdx.z) * g.d + k0) + c * 16;
+      *reinterpret_cast<u32x4*>(ldsA + row * P + c * 16) = *reinterpret_cast<const u32x4*>(src);
+    }
+    stage_w<T>((const T*)tk.w, g.d, n0, tk.n, k0, ldsW, tid);
+    __syncthreads();
+    mma_chunk<T>(ldsA, ldsW, wr, wc, lane, acc);
+    __syncthreads();
+  }
+  const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wc * 64 + j * 32 + r;
+    if (n >= tk.n) continue;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int b = b0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+      if (b < g.B) {
+        const int64_t o = (int64_t)b * g.D + tk.off + n;
+        g.out[o] = acc[j][e] + (g.resid ? g.resid[o] : 0.f);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int gpt_scalar_tokens(const int64_t* t, const void* loss_target, const void* loss_prev, int loss_is_f64,
+                                 const float* freqs, int nfreq, int n_scalar, float* out, int B, void* stream) {
+  GPT_REQUIRE(t && loss_target && loss_prev && freqs && out, "gpt_scalar_tokens: null operand");
+  GPT_REQUIRE(B > 0 && nfreq > 0 && (n_scalar == 2 || n_scalar == 4), "gpt_scalar_tokens: bad sizes");
+  const int64_t total = (int64_t)B * n_scalar * (2 * nfreq + 1);
+  hipLaunchKernelGGL(scalar_tokens_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t,
+                     loss_target, loss_prev, loss_is_f64, freqs, nfreq, n_scalar, out, B);
+  return gpt_launch_status("gpt_scalar_tokens");
+}
+
+extern "C" int gpt_encode_tokens(int dtype, int n_tok, const float* const* host_src, const int64_t* host_src_ld,
+                                 const void* const* host_w, const int64_t* host_w_ld, const int* host_k, float* out,
+                                 int B, int d, void* stream) {
+  GPT_REQUIRE(dtype == GPT_F32 || dtype == GPT_BF16, "gpt_encode_tokens: bad dtype %d", dtype);
+  GPT_REQUIRE(n_tok > 0 && n_tok <= MAX_TOK, "gpt_encode_tokens: n_tok=%d out of range (max %d)", n_tok, MAX_TOK);
+  GPT_REQUIRE(B > 0 && d > 0 && d % 8 == 0 && out, "gpt_encode_tokens: bad sizes");
+  const int esz = dtype == GPT_BF16 ? 2 : 4;
+  EncArgs g;
+  for (int i = 0; i < n_tok; ++i) {
+    GPT_REQUIRE(host_src[i] && host_w[i] && host_k[i] > 0, "gpt_encode_tokens: token %d: null/empty", i);
+    const int kp = (host_k[i] + KC - 1) / KC * KC;
+    GPT_REQUIRE(host_w_ld[i] >= kp && (host_w_ld[i] * esz) % 16 == 0 && ((uintptr_t)host_w[i] % 16) == 0,
+                "gpt_encode_tokens: token %d: weight rows must be zero-padded to a multiple of %d and 16-byte aligned", i, KC);
+    GPT_REQUIRE(host_src_ld[i] >= host_k[i], "gpt_encode_tokens: token %d: src_ld < k", i);
+    g.tok[i] = EncTok{host_src[i], host_w[i], host_src_ld[i], host_w_ld[i], host_k[i]};
+  }
+  g.out = out; g.n_tok = n_tok; g.B = B; g.d = d;
+  const dim3 grid((d + TN - 1) / TN, (B + TB - 1) / TB, n_tok), block(256);
+  if (dtype == GPT_BF16) hipLaunchKernelGGL(encode_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL(encode_kernel<float>, grid, block, 0, (hipStream_t)stream, g);
+  return gpt_launch_status("gpt_encode_tokens");
+}
+
+extern "C" int gpt_decode_tokens(int dtype, int n_tok, const void* feat, int T, const void* const* host_w,
+                                 const int* host_n, const int* host_off, const float* resid, float* out, int B, int d,
+                                 int D, void* stream) {
+  GPT_REQUIRE(dtype == GPT_F32 || dtype == GPT_BF16, "gpt_decode_tokens: bad dtype %d", dtype);
+  GPT_REQUIRE(n_tok > 0 && n_tok <= MAX_TOK && n_tok <= T, "gpt_decode_tokens: n_tok=%d out of range", n_tok);
+  GPT_REQUIRE(B > 0 && d > 0 && d % KC == 0 && D > 0 && feat && out, "gpt_decode_tokens: bad sizes (d must be a multiple of %d)", KC);
+  GPT_REQUIRE(((uintptr_t)feat % 16) == 0, "gpt_decode_tokens: feat must be 16-byte aligned");
+  DecArgs g;
+  int max_n = 0;
+  for (int j = 0; j < n_tok; ++j) {
+    GPT_REQUIRE(host_w[j] && host_n[j] > 0 && host_off[j] >= 0 && host_off[j] + host_n[j] <= D,
+                "gpt_decode_tokens: token %d: bad descriptor", j);
+    GPT_REQUIRE(((uintptr_t)host_w[j] % 16) == 0, "gpt_decode_tokens: token %d: weight must be 16-byte aligned", j);
+    g.tok[j] = DecTok{host_w[j], host_n[j], host_off[j]};
+    max_n = host_n[j] > max_n ? host_n[j] : max_n;
+  }
+  g.feat = feat; g.resid = resid; g.out = out; g.n_tok = n_tok; g.T = T; g.B = B; g.d = d; g.D = D;
+  const dim3 grid((max_n + TN - 1) / TN, (B + TB - 1) / TB, n_tok), block(256);
+  if (dtype == GPT_BF16) hipLaunchKernelGGL(decode_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL(decode_kernel<float>, grid, block, 0, (hipStream_t)stream, g);
+  return gpt_launch_status("gpt_decode_tokens");
+}

@@ -1,0 +1,147 @@
+"""Data-parallel layer: the reference's Gpt/distributed.py helper functions (live ones only, :35-72 and
+:142-189) on torch.distributed, whose "nccl" backend is RCCL over xGMI on ROCm, plus the gradient
+exchange used by the training step (reference: DistributedDataParallel, main.py:229-240).
+
+One process per GPU; single-process calls short-circuit exactly as the reference's do."""
+import torch
+import torch.distributed as dist
+
+
+def _live():
+    return dist.is_available() and dist.is_initialized()
+
+
+def is_main_proc(local=False):
+    return (not _live()) or dist.get_rank() == 0
+
+
+def get_rank():
+    return dist.get_rank() if _live() else 0
+
+
+def get_world_size():
+    return dist.get_world_size() if _live() else 1
+
+
+def synchronize():
+    if get_world_size() > 1:
+        dist.barrier()
+
+
+def scaled_all_reduce(cfg, tensors):
+    """In-place SUM all-reduce scaled by 1/num_gpus; returns the list (distributed.py:50-72).
+    The tensors are reduced as ONE flat message instead of one collective each."""
+    if cfg.num_gpus == 1:
+        return tensors
+    if len(tensors) == 1:
+        dist.all_reduce(tensors[0])
+        tensors[0].mul_(1.0 / cfg.num_gpus)
+        return tensors
+    flat = torch.cat([t.reshape(-1).float() for t in tensors])
+    dist.all_reduce(flat)
+    flat.mul_(1.0 / cfg.num_gpus)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t))
+        off += n
+    return tensors
+
+
+def all_gather(input, cat=True, dim=0):
+    """distributed.py:170-183."""
+    if get_world_size() == 1:
+        return input if cat else input.unsqueeze(dim)
+    parts = [torch.empty_like(input) for _ in range(get_world_size())]
+    dist.all_gather(parts, input.contiguous())
+    return torch.cat(parts, dim=dim) if cat else torch.stack(parts, dim=dim)
+
+
+def rank0_to_all(input, cat=True):
+    """Rank 0's value on every rank (distributed.py:186-189) as a broadcast."""
+    if get_world_size() == 1:
+        return (input if cat else input.unsqueeze(0))[0]
+    out = input.clone()
+    dist.broadcast(out, src=0)
+    return (out if cat else out.unsqueeze(0))[0]
+
+
+def shard_rows(n_rows, rank=None, world=None):
+    """Contiguous row block [lo, hi) of a batch sharded for sampling (no traffic until the final gather)."""
+    rank = get_rank() if rank is None else rank
+    world = get_world_size() if world is None else world
+    per = (n_rows + world - 1) // world
+    lo = min(rank * per, n_rows)
+    return lo, min(lo + per, n_rows)
+
+
+def gather_rows(local, n_rows):
+    """Final gather of row-sharded samples: (B_local, D) per rank -> (n_rows, D) on every rank."""
+    world = get_world_size()
+    if world == 1:
+        return local
+    per = (n_rows + world - 1) // world
+    pad = torch.zeros(per, *local.shape[1:], dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    return torch.cat(parts, 0)[:n_rows]
+
+
+def broadcast_parameters(module, src=0):
+    """Initial parameter broadcast from rank 0 (what DDP does at construction, main.py:231-236)."""
+    if get_world_size() == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src)
+
+
+class GradBuckets:
+    """Gradient all-reduce (SUM then / world) over a few large flat buckets.
+
+    The parameters' .grad tensors are views into flat fp32 buckets, so the exchange is `n_buckets` large
+    RCCL all-reduces with no packing copies; a bucket is launched (async) as soon as the backward has
+    produced every gradient in it, overlapping the exchange with the rest of the backward."""
+
+    def __init__(self, params, bucket_bytes=256 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets, self.index = [], {}
+        cur, cur_n = [], 0
+        for p in reversed(self.params):                  # backward produces the last layers first
+            cur.append(p)
+            cur_n += p.numel()
+            if cur_n * 4 >= bucket_bytes:
+                self._close(cur)
+                cur, cur_n = [], 0
+        if cur:
+            self._close(cur)
+        self.pending = []
+
+    def _close(self, plist):
+        n = sum(p.numel() for p in plist)
+        flat = torch.zeros(n, dtype=torch.float32, device=plist[0].device)
+        off = 0
+        for p in plist:
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            self.index[id(p)] = len(self.buckets)
+            off += p.numel()
+        self.buckets.append(flat)
+
+    def zero(self):
+        for b in self.buckets:
+            b.zero_()
+
+    def launch(self, bucket_id):
+        if get_world_size() > 1:
+            self.pending.append((bucket_id, dist.all_reduce(self.buckets[bucket_id], async_op=True)))
+
+    def launch_all(self):
+        for i in range(len(self.buckets)):
+            self.launch(i)
+
+    def wait(self):
+        w = get_world_size()
+        for i, h in self.pending:
+            h.wait()
+            self.buckets[i].mul_(1.0 / w)
+        self.pending = []

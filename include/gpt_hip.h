@@ -1,0 +1,209 @@
+/* gpt_hip.h - C ABI of the MI355X (gfx950) G.pt denoiser hot path.
+ *
+ * The reference (wpeebles/G.pt) has no FFI: its hot path sits behind a Python call boundary
+ * (SURVEY.md section 8b).  Each entry point below replaces the ATen dispatches of the cited
+ * reference lines; the Python host in g.pt_amd/ binds them with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless named host_*; sizes are element counts;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - `dtype` selects the activation/weight type of the MFMA contractions:
+ *        GPT_F32  = exact fp32 (v_mfma_f32_32x32x2_f32), the parity mode,
+ *        GPT_BF16 = bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16);
+ *     residual stream, LayerNorm/softmax statistics, biases and all DDPM arithmetic are fp32 in both;
+ *   - return value: 0 = ok; negative = rejected before any launch (bad shape / alignment / enum);
+ *     positive = a hipError_t from the launch.  gpt_last_error() gives the message.
+ *   - no entry point allocates, frees or synchronises; all are stream-ordered and graph-capturable.
+ */
+#ifndef GPT_HIP_H
+#define GPT_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPT_F32 0
+#define GPT_BF16 1
+
+/* epilogues of gpt_gemm_nt */
+#define GPT_EPI_STORE 0     /* C(dtype)  = acc + bias                                   */
+#define GPT_EPI_GELU 1      /* C(dtype)  = gelu_erf(acc + bias)          nn.GELU()      */
+#define GPT_EPI_RESADD 2    /* C(fp32)   = R + acc + bias, R = aux (fp32, ldaux) if aux != NULL else C   x = x + f(x) */
+#define GPT_EPI_STORE_F32 3 /* C(fp32)   = acc + bias                                   */
+#define GPT_EPI_GELU_AUX 4  /* aux(dtype) = acc + bias ; C(dtype) = gelu(aux)  (training: keeps pre-activation) */
+#define GPT_EPI_DGELU 5     /* C(dtype)  = acc * gelu'(aux)              (backward of GELU) */
+#define GPT_EPI_ACCUM_F32 6 /* C(fp32)  += acc                           (gradient accumulation) */
+
+const char* gpt_last_error(void);
+int gpt_abi_version(void);
+
+/* C[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N]).  A, W: `dtype`, row-major, leading dims lda/ldw in
+ * elements, K % 64 == 0 (bf16) or K % 32 == 0 (fp32), 16-byte aligned rows.  bias: fp32 or NULL.
+ * Replaces nn.Linear on the path: Gpt/models/transformer.py:38-40 (q,k,v), :50 (proj), :63-65 (mlp). */
+int gpt_gemm_nt(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                void* C, int64_t ldc, void* aux, int64_t ldaux, int M, int N, int K, int epilogue,
+                void* stream);
+
+/* y[rows, d](out_dtype) = LayerNorm(x[rows, d] fp32; gamma, beta fp32, eps) (+ add[(row % add_rows), d] fp32).
+ * out_dtype: GPT_F32 or GPT_BF16.  Optionally writes mean/rstd (fp32, per row) for the backward.
+ * Replaces nn.LayerNorm at transformer.py:70-71 (ln1, ln2), :226 (ln_in, fused with the pos_emb add of
+ * :308-309 through add/add_rows), :311 (ln_f). */
+int gpt_layernorm(const float* x, const float* gamma, const float* beta, const float* add, int add_rows,
+                  void* y, int out_dtype, float* mean, float* rstd, int rows, int d, float eps, void* stream);
+
+/* Non-causal multi-head attention over T <= 32 tokens.  qkv: [B*T, 3*d] (`dtype`), columns
+ * [0,d) = query, [d,2d) = key, [2d,3d) = value, head h at columns h*hd..; y: [B*T, d] (`dtype`).
+ * hd = d / n_head must be a multiple of 32 and <= 128.  Replaces transformer.py:43-47. */
+int gpt_attention(int dtype, const void* qkv, void* y, int B, int T, int n_head, int hd, void* stream);
+
+/* Scalar tokens: out[b, j*W .. (j+1)*W) = [sin(f*s_j), cos(f*s_j), s_j],  W = 2*nfreq+1,
+ * j = 0: s = t[b] (int64 timestep); j = 1: s = fp32(lt - lp); j = 2: fp32(lt); j = 3: fp32(lp), where the
+ * subtraction is done in float64 when loss_is_f64 (inputs are float64) and in fp32 otherwise, exactly as
+ * transformer.py:431 subtracts before the cast of :329.  n_scalar = 2 (delta only) or 4 (absolute).
+ * out: fp32 [B, n_scalar*W].  Replaces FrequencyEmbedder.forward (:324-334) x4 and embed_loss (:427-438). */
+int gpt_scalar_tokens(const int64_t* t, const void* loss_target, const void* loss_prev, int loss_is_f64,
+                      const float* freqs, int nfreq, int n_scalar, float* out, int B, void* stream);
+
+/* Ragged per-token encoder: for token i, out[b, i, :] = src_i[b, 0:k_i] . W_i[d, k_i]^T.
+ * Token descriptors are host arrays (copied into kernel arguments, <= 64 tokens): src pointer (fp32,
+ * row stride src_ld[i]), weight pointer (`dtype`, row stride w_ld[i] >= k_i), k_i.
+ * out: fp32 [B, n_tok, d].  Replaces GPT.encode_parameters' split + 26 Linears + stack
+ * (transformer.py:221-225) without materialising the (B,16948) concatenation of :458-459. */
+int gpt_encode_tokens(int dtype, int n_tok, const float* const* host_src, const int64_t* host_src_ld,
+                      const void* const* host_w, const int64_t* host_w_ld, const int* host_k,
+                      float* out, int B, int d, void* stream);
+
+/* Ragged per-token decoder + global residual: for j < n_tok,
+ * out[b, off_j .. off_j+n_j) = feat[b, j, :] . W_j[n_j, d]^T + resid[b, off_j ..].
+ * feat: `dtype` [B, T, d]; out/resid: fp32 [B, D] (resid may be NULL).
+ * Replaces GPT.decode_parameters (transformer.py:230-242) and the residual of :462-463. */
+int gpt_decode_tokens(int dtype, int n_tok, const void* feat, int T, const void* const* host_w,
+                      const int* host_n, const int* host_off, const float* resid, float* out,
+                      int B, int d, int D, void* stream);
+
+/* DDPM elementwise kernels.  `coef` is a device fp32 table [n_steps, GPT_DDPM_NCOEF] built on the host in
+ * float64 and cast once (the reference casts per gather, gaussian_diffusion.py:864); t: int64 [B]. */
+#define GPT_DDPM_NCOEF 8
+#define GPT_C_SQRT_AC 0      /* sqrt_alphas_cumprod            */
+#define GPT_C_SQRT_1MAC 1    /* sqrt_one_minus_alphas_cumprod  */
+#define GPT_C_POST1 2        /* posterior_mean_coef1           */
+#define GPT_C_POST2 3        /* posterior_mean_coef2           */
+#define GPT_C_LOGVAR 4       /* model log variance (FIXED_LARGE or FIXED_SMALL) */
+#define GPT_C_RECIP 5        /* sqrt_recip_alphas_cumprod      */
+#define GPT_C_RECIPM1 6      /* sqrt_recipm1_alphas_cumprod    */
+#define GPT_C_SPARE 7
+
+/* x_t = sqrt_ac[t] x0 + sqrt_1mac[t] noise            gaussian_diffusion.py:209-224 */
+int gpt_q_sample(const float* x0, const float* noise, const int64_t* t, const float* coef, float* x_t,
+                 int B, int D, void* stream);
+
+/* One reverse step, fused (gaussian_diffusion.py:301-317 + :404-410):
+ *   x0 = model_out                       (predict_xstart)   or  recip[t] x_t - recipm1[t] model_out
+ *   x0 = clamp(x0, lo, hi) if use_clamp  (denoised_fn 'static' thresholding / clip_denoised)
+ *   x_prev = post1[t] x0 + post2[t] x_t + (t != 0) exp(0.5 logvar[t]) noise
+ * Writes x_out (may alias x_t) and optionally pred_xstart.  noise == NULL: the mean only (p_mean_variance). */
+int gpt_posterior_step(const float* model_out, const float* x_t, const float* noise, const int64_t* t,
+                       const float* coef, int predict_xstart, int use_clamp, float lo, float hi,
+                       float* x_out, float* pred_xstart, int B, int D, void* stream);
+
+/* mse[b] = mean_d (target - out)^2   (diffusion_utils.py:8-12 over gaussian_diffusion.py:773) */
+int gpt_mse_rows(const float* target, const float* out, float* mse, int B, int D, void* stream);
+/* grad_out[b, :] = scale[b] * 2 (out - target) / D     (backward of the above; scale = dL/dmse) */
+int gpt_mse_rows_bwd(const float* target, const float* out, const float* scale, float* grad_out,
+                     int B, int D, void* stream);
+
+/* Philox4x32-10 standard normal fill (Box-Muller), counter = element index, key = (seed, stream_id). */
+int gpt_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
+/* out[i] = value, int64 (timestep vectors of the sampling loop, gaussian_diffusion.py:493) */
+int gpt_fill_i64(int64_t* out, int64_t n, int64_t value, void* stream);
+
+/* dtype conversion helpers (packed bf16 weight copies; round-to-nearest-even). */
+int gpt_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+int gpt_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
+/* dst[c, r] = src[r, c]  for a row-major [rows, cols] matrix of `dtype`. */
+int gpt_transpose(int dtype, const void* src, void* dst, int rows, int cols, void* stream);
+
+/* Permutation augmentation (Gpt/data/augment.py:25-75 with data_gen/train_mnist.py:28-50 and
+ * data_gen/train_cifar10.py:27-47).  perms: int32 device array [n_samples, perm_len] holding, per sample,
+ * the hidden-unit permutations back to back (MLP: p[H]; CNN: p1[C1] then p2[C2]).
+ * index: int64 [n_samples, D]. */
+int gpt_perm_index_mlp(const int32_t* perms, int64_t* index, int n_samples, int n_in, int hidden, int n_out,
+                       void* stream);
+int gpt_perm_index_cnn(const int32_t* perms, int64_t* index, int n_samples, int c_in, int c1, int c2, int ksz,
+                       int n_out, void* stream);
+/* dst[s, i] = src[s, index[s, i]] for n_nets tensors sharing the index (both checkpoints of a pair). */
+int gpt_perm_gather(const float* const* host_src, float* const* host_dst, int n_nets, const int64_t* index,
+                    int n_samples, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole-path entry points: one host call launches every kernel of a denoiser forward / of the whole
+ * reverse-diffusion loop on `stream` (no host synchronisation, no allocation), so the Python caller pays
+ * one FFI crossing per forward instead of ~90.  All pointers inside the structs are device pointers,
+ * the structs themselves live in host memory.
+ * ------------------------------------------------------------------------------------------------ */
+#define GPT_MAX_TOKENS 40
+#define GPT_SRC_X 0       /* token is a slice of the noised vector x          */
+#define GPT_SRC_XPREV 1   /* token is a slice of the starting vector x_prev   */
+#define GPT_SRC_SCALAR 2  /* token is one frequency-embedded scalar           */
+
+typedef struct {
+  const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+  const void* wqkv;  const float* bqkv;    /* [3d, d] rows = query | key | value, (dtype); [3d] fp32 */
+  const void* wproj; const float* bproj;   /* [d, d]   */
+  const void* w1;    const float* b1;      /* [4d, d]  */
+  const void* w2;    const float* b2;      /* [d, 4d]  */
+} gpt_layer_t;
+
+typedef struct {
+  int dtype, d, n_head, n_layer, T, D, nfreq, n_scalar, n_in_tok, n_out_tok;
+  const float* freqs;                      /* [nfreq] */
+  const float* pos_emb;                    /* [T, d] */
+  const float *ln_in_w, *ln_in_b, *ln_f_w, *ln_f_b;
+  const void* enc_w[GPT_MAX_TOKENS];       /* (dtype) [d, enc_w_ld], zero padded to a multiple of 32 */
+  int64_t enc_w_ld[GPT_MAX_TOKENS];
+  int enc_k[GPT_MAX_TOKENS], enc_src[GPT_MAX_TOKENS], enc_off[GPT_MAX_TOKENS];
+  const void* dec_w[GPT_MAX_TOKENS];       /* (dtype) [dec_n, d] */
+  int dec_n[GPT_MAX_TOKENS], dec_off[GPT_MAX_TOKENS];
+  const gpt_layer_t* layers;               /* host array [n_layer] */
+} gpt_model_t;
+
+/* Activations.  With layer_stride == 0 every layer reuses the same buffers (inference); with
+ * layer_stride == 1 buffer `p` of layer l lives at p + l * (its per-layer size), which keeps what the
+ * backward needs.  M = B_max * T rows. */
+typedef struct {
+  int B_max, layer_stride;
+  float* scal;     /* [B, n_scalar * (2 nfreq + 1)]                                  */
+  float* enc;      /* [M, d]   encoder output before ln_in                           */
+  float* x;        /* [(2 n_layer + 1) if stride else 1][M, d]  residual stream      */
+  void* h1;        /* (dtype) [L?][M, d]   ln1 output                                */
+  void* qkv;       /* (dtype) [L?][M, 3d]                                            */
+  void* att;       /* (dtype) [L?][M, d]   attention output                          */
+  void* h2;        /* (dtype) [L?][M, d]   ln2 output                                */
+  void* pre;       /* (dtype) [L][M, 4d]   fc1 pre-activation (stride mode only)     */
+  void* act;       /* (dtype) [L?][M, 4d]  gelu output                               */
+  void* hf;        /* (dtype) [M, d]       ln_f output                               */
+  float* stats;    /* fp32 [(2 L + 2)][2][M]  LayerNorm mean / rstd (stride mode only, else NULL) */
+} gpt_workspace_t;
+
+/* out[B, D] = Gpt.forward(x, t, loss_target, loss_prev, x_prev)   (transformer.py:440-464) */
+int gpt_denoiser_forward(const gpt_model_t* m, const gpt_workspace_t* ws, const float* x, const int64_t* t,
+                         const void* loss_target, const void* loss_prev, int loss_is_f64, const float* x_prev,
+                         float* out, int B, void* stream);
+
+/* The whole p_sample_loop (gaussian_diffusion.py:458-505) for one batch, in place on x[B, D]:
+ * for i = n_steps-1 .. 0:  out = denoiser(x, timestep_map[i]);  x = posterior_step(out, x, noise_i, i).
+ * noise: NULL -> in-kernel Philox with (seed, i);  else fp32 [n_steps, B, D] holding the noise drawn at index i
+ * in slab i (injected-noise parity mode).  t_model / t_index: int64 [B] scratch; model_out: fp32 [B, D] scratch;
+ * noise_buf: fp32 [B, D] scratch (Philox mode).  host_timestep_map: int64 host array [n_steps]. */
+int gpt_sample_loop(const gpt_model_t* m, const gpt_workspace_t* ws, float* x, const void* loss_target,
+                    const void* loss_prev, int loss_is_f64, const float* x_prev, const float* coef,
+                    const int64_t* host_timestep_map, int n_steps, int first_step, int last_step,
+                    int predict_xstart, int use_clamp, float lo, float hi,
+                    const float* noise, uint64_t seed, int64_t* t_model, int64_t* t_index, float* model_out,
+                    float* noise_buf, int B, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,304 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the oracle and the committed golden
+fixtures (which were produced by the reference itself).  Run on the MI355X box: pytest -m gpu.
+
+Tolerances.  fp32 mode: BASELINE.json asks for 1e-3 relative error on the denoiser output; the tests
+hold the fp32 path to 2e-4 relative-to-scale.  bf16 mode is a throughput mode (bf16 operands, fp32
+accumulate): held to 3e-2 of the output scale."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import denoiser as od          # noqa: E402
+from oracle import diffusion as odf        # noqa: E402
+from oracle import permute as op           # noqa: E402
+from tests.cases import CASES, block_case, gpt_kwargs, make_inputs, step_noise  # noqa: E402
+
+import gpt_amd                              # noqa: E402
+from gpt_amd import _lib as L               # noqa: E402
+
+DEV = "cuda:0"
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def plan_of(case, predict_xstart=True):
+    c = CASES[case]
+    return od.Plan(c["parameter_sizes"], 128, 14, True, c["n_head"], c["n_embd"], c["n_layer"],
+                   c["chunk_size"], c["split_policy"], predict_xstart)
+
+
+def build(case, dtype="fp32", seed=0):
+    plan = plan_of(case)
+    sd = od.random_state_dict(plan, seed=seed)
+    m = gpt_amd.Gpt(**gpt_kwargs(case))
+    m.load_state_dict(sd)
+    return m.to(DEV).eval().set_compute_dtype(dtype), plan, sd
+
+
+# ------------------------------------------------------------------------------------------ kernels
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-5), ("bf16", 1e-2)])
+@pytest.mark.parametrize("M,N,K", [(104, 192, 192), (104, 576, 192), (300, 768, 192), (128, 128, 64), (1664, 1536, 1536),
+                                   (77, 130, 256)])
+def test_gemm_epilogues(dtype, tol, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
+    bias, R = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    code = L.dtype_code(dtype)
+    td = L.torch_dtype(code)
+    Ad, Wd = A.to(DEV).to(td), W.to(DEV).to(td)
+    Af, Wf = Ad.float().cpu(), Wd.float().cpu()              # what the kernel actually sees
+    ref = Af.double() @ Wf.double().t() + bias.double()
+    lib = L.lib()
+
+    bias_d = bias.to(DEV)
+
+    def run(epi, Cbuf, aux=None, ldaux=0, use_bias=True):
+        L.check(lib.gpt_gemm_nt(code, L.ptr(Ad), K, L.ptr(Wd), K, L.ptr(bias_d) if use_bias else None, L.ptr(Cbuf), N,
+                                L.ptr(aux), ldaux, M, N, K, epi, L.stream()), "gemm")
+        torch.cuda.synchronize()
+
+    out = torch.empty(M, N, dtype=td, device=DEV)
+    run(L.EPI_STORE, out)
+    assert rel_err(out.float().cpu(), ref) < tol
+    run(L.EPI_GELU, out)
+    assert rel_err(out.float().cpu(), torch.nn.functional.gelu(ref)) < tol
+    acc = R.to(DEV).clone()
+    run(L.EPI_RESADD, acc)
+    assert rel_err(acc.cpu(), R.double() + ref) < tol
+    acc2, Rd = torch.empty(M, N, device=DEV), R.to(DEV)
+    run(L.EPI_RESADD, acc2, aux=Rd, ldaux=N)
+    assert rel_err(acc2.cpu(), R.double() + ref) < tol
+    f32o = torch.empty(M, N, device=DEV)
+    run(L.EPI_STORE_F32, f32o, use_bias=False)
+    assert rel_err(f32o.cpu(), ref - bias.double()) < tol
+    pre = torch.empty(M, N, dtype=td, device=DEV)
+    run(L.EPI_GELU_AUX, out, aux=pre, ldaux=N)
+    assert rel_err(pre.float().cpu(), ref) < tol
+    assert rel_err(out.float().cpu(), torch.nn.functional.gelu(ref)) < tol
+
+
+def test_gemm_rejects_bad_shapes():
+    a = torch.zeros(8, 48, device=DEV)
+    st = L.lib().gpt_gemm_nt(L.F32, L.ptr(a), 48, L.ptr(a), 48, None, L.ptr(a), 8, None, 0, 8, 8, 48, 0, L.stream())
+    assert st < 0 and b"multiple" in L.lib().gpt_last_error()
+
+
+@pytest.mark.parametrize("d", [192, 256, 1536, 2048, 520])
+@pytest.mark.parametrize("out_dtype", ["fp32", "bf16"])
+def test_layernorm(d, out_dtype):
+    g = torch.Generator().manual_seed(d)
+    rows = 53
+    x = torch.randn(rows, d, generator=g) * 3 + 0.5
+    w, b = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    pos = torch.randn(26, d, generator=g)
+    ref = torch.nn.functional.layer_norm(x, (d,), w, b, 1e-5)
+    code = L.dtype_code(out_dtype)
+    y = torch.empty(rows, d, dtype=L.torch_dtype(code), device=DEV)
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    xd, wd, bd, pd = x.to(DEV), w.to(DEV), b.to(DEV), pos.to(DEV)       # keep the device tensors alive
+    L.check(L.lib().gpt_layernorm(L.ptr(xd), L.ptr(wd), L.ptr(bd), None, 0, L.ptr(y), code,
+                                  L.ptr(mean), L.ptr(rstd), rows, d, 1e-5, L.stream()), "ln")
+    tol = 1e-5 if out_dtype == "fp32" else 1e-2
+    assert rel_err(y.float().cpu(), ref) < tol
+    np.testing.assert_allclose(mean.cpu().numpy(), x.mean(1).numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rstd.cpu().numpy(), (1 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)).numpy(), rtol=1e-5)
+    L.check(L.lib().gpt_layernorm(L.ptr(xd), L.ptr(wd), L.ptr(bd), L.ptr(pd), 26, L.ptr(y),
+                                  code, None, None, rows, d, 1e-5, L.stream()), "ln+add")
+    ref2 = ref + pos[torch.arange(rows) % 26]
+    assert rel_err(y.float().cpu(), ref2) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-5), ("bf16", 1.5e-2)])
+@pytest.mark.parametrize("H,hd,T", [(2, 96, 26), (2, 128, 26), (16, 96, 26), (3, 32, 18), (2, 64, 32), (1, 96, 5)])
+def test_attention(dtype, tol, H, hd, T):
+    g = torch.Generator().manual_seed(H * hd + T)
+    B, d = 5, H * hd
+    code = L.dtype_code(dtype)
+    td = L.torch_dtype(code)
+    qkv = (torch.randn(B * T, 3 * d, generator=g)).to(DEV).to(td)
+    f = qkv.float().cpu().view(B, T, 3, H, hd)
+    q, k, v = (f[:, :, i].transpose(1, 2).double() for i in range(3))
+    att = torch.softmax(q @ k.transpose(-2, -1) / np.sqrt(hd), dim=-1)
+    ref = (att @ v).transpose(1, 2).reshape(B * T, d)
+    y = torch.empty(B * T, d, dtype=td, device=DEV)
+    L.check(L.lib().gpt_attention(code, L.ptr(qkv), L.ptr(y), B, T, H, hd, L.stream()), "attention")
+    assert rel_err(y.float().cpu(), ref) < tol
+
+
+def test_scalar_tokens_golden(golden):
+    g = golden("g2_freq")
+    emb = gpt_amd.FrequencyEmbedder(128, 14).to(DEV)
+    assert np.array_equal(emb.frequencies.cpu().numpy(), g["frequencies"])
+    # sin/cos of arguments up to 1.6e7 rad: device libm vs host libm may differ in the last ulp of the result
+    np.testing.assert_allclose(emb(torch.from_numpy(g["t"]).to(DEV)).cpu().numpy(), g["t_emb"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(emb(torch.from_numpy(g["l32"]).to(DEV)).cpu().numpy(), g["l32_emb"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(emb(torch.from_numpy(g["l64"]).to(DEV)).cpu().numpy(), g["l64_emb"], rtol=0, atol=2e-6)
+
+
+# ------------------------------------------------------------------------------------------ denoiser
+@pytest.mark.parametrize("case", ["mnist_small", "cifar_small"])
+def test_forward_golden_fp32(golden, case):
+    g = golden(f"g3_forward_{case}")
+    m, plan, sd = build(case, "fp32")
+    x, t, lt, lp, xp = (v.to(DEV) for v in make_inputs(case, B=4, seed=11))
+    with torch.no_grad():
+        out = m(x, t, lt, loss_prev=lp, x_prev=xp)
+        out_col = m(x, t, lt.view(-1, 1).double(), loss_prev=lp.view(-1, 1).double(), x_prev=xp)
+    # error relative to the scale of the network's own contribution (out - x_prev), the strict reading
+    delta_scale = np.abs(g["out"] - xp.cpu().numpy()).max()
+    assert np.abs(out.cpu().numpy() - g["out"]).max() / delta_scale < 2e-4
+    assert np.abs(out_col.cpu().numpy() - g["out_col64"]).max() / delta_scale < 2e-4
+    # intermediates from the workspace: pre-decode features
+    hf = m.engine().buffers()["hf"].float().cpu().view(4, plan.T, plan.n_embd)
+    assert rel_err(hf, g["ln_f"]) < 2e-4
+
+
+@pytest.mark.parametrize("case", ["mnist_small", "cifar_small"])
+def test_forward_oracle_bf16(case):
+    m, plan, sd = build(case, "bf16", seed=3)
+    cpu = make_inputs(case, B=7, seed=5)
+    x, t, lt, lp, xp = (v.to(DEV) for v in cpu)
+    with torch.no_grad():
+        out = m(x, t, lt, loss_prev=lp, x_prev=xp)
+        ref = od.forward(sd, plan, *cpu)
+    delta = (ref - cpu[4]).numpy()
+    assert np.abs(out.cpu().numpy() - ref.numpy()).max() / np.abs(delta).max() < 3e-2
+
+
+@pytest.mark.parametrize("name,d,H", [("mnist", 1536, 16), ("cifar", 2048, 16)])
+def test_full_width_block_golden(golden, name, d, H):
+    """One full-width Block (transformer.py:54-72) assembled from the per-kernel C ABI, fp32."""
+    g = golden("g4_block")
+    sd, xin = block_case(d)
+    w = {k: v.to(DEV) for k, v in sd.items()}
+    lib, s = L.lib(), L.stream()
+    M = xin.shape[0] * xin.shape[1]
+    x = xin.reshape(M, d).to(DEV).clone()
+    h = torch.empty(M, d, device=DEV)
+    wqkv = torch.cat([w["attn.query.weight"], w["attn.key.weight"], w["attn.value.weight"]]).contiguous()
+    bqkv = torch.cat([w["attn.query.bias"], w["attn.key.bias"], w["attn.value.bias"]]).contiguous()
+    qkv, att, act = torch.empty(M, 3 * d, device=DEV), torch.empty(M, d, device=DEV), torch.empty(M, 4 * d, device=DEV)
+    L.check(lib.gpt_layernorm(L.ptr(x), L.ptr(w["ln1.weight"]), L.ptr(w["ln1.bias"]), None, 0, L.ptr(h), 0, None, None, M, d, 1e-5, s), "ln1")
+    L.check(lib.gpt_gemm_nt(0, L.ptr(h), d, L.ptr(wqkv), d, L.ptr(bqkv), L.ptr(qkv), 3 * d, None, 0, M, 3 * d, d, L.EPI_STORE, s), "qkv")
+    L.check(lib.gpt_attention(0, L.ptr(qkv), L.ptr(att), 2, 26, H, d // H, s), "att")
+    L.check(lib.gpt_gemm_nt(0, L.ptr(att), d, L.ptr(w["attn.proj.weight"]), d, L.ptr(w["attn.proj.bias"]), L.ptr(x), d, None, 0, M, d, d, L.EPI_RESADD, s), "proj")
+    L.check(lib.gpt_layernorm(L.ptr(x), L.ptr(w["ln2.weight"]), L.ptr(w["ln2.bias"]), None, 0, L.ptr(h), 0, None, None, M, d, 1e-5, s), "ln2")
+    L.check(lib.gpt_gemm_nt(0, L.ptr(h), d, L.ptr(w["mlp.0.weight"]), d, L.ptr(w["mlp.0.bias"]), L.ptr(act), 4 * d, None, 0, M, 4 * d, d, L.EPI_GELU, s), "fc1")
+    L.check(lib.gpt_gemm_nt(0, L.ptr(act), 4 * d, L.ptr(w["mlp.2.weight"]), 4 * d, L.ptr(w["mlp.2.bias"]), L.ptr(x), d, None, 0, M, d, 4 * d, L.EPI_RESADD, s), "fc2")
+    y = x.cpu().view(2, 26, d).numpy()
+    assert np.abs(y - g[f"{name}_y"]).max() / np.abs(g[f"{name}_y"] - xin.numpy()).max() < 2e-4
+
+
+# ------------------------------------------------------------------------------------------ diffusion
+@pytest.mark.parametrize("D", [7960, 5370, 33])
+def test_q_sample_and_posterior_bit_exact(D):
+    """The elementwise DDPM kernels reproduce the oracle's fp32 arithmetic bit for bit (same roundings)."""
+    B = 6
+    g = torch.Generator().manual_seed(D)
+    x0, nz, xt, mo = (torch.randn(B, D, generator=g) for _ in range(4))
+    t = torch.tensor([0, 1, 17, 500, 998, 999])
+    diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
+    tb = odf.Tables(1000)
+    got = diff.q_sample(x0.to(DEV), t.to(DEV), noise=nz.to(DEV)).cpu()
+    assert torch.equal(got, odf.q_sample(tb, x0, t, nz))
+    for px, clamp in ((True, None), (False, None), (True, (-0.5, 0.7)), (False, (-1.0, 1.0))):
+        diff.model_mean_type = gpt_amd.ModelMeanType.START_X if px else gpt_amd.ModelMeanType.EPSILON
+        out, x0p = diff._posterior(mo.to(DEV), xt.to(DEV), nz.to(DEV), t.to(DEV), clamp, want_xstart=True)
+        ref, ref0 = odf.posterior_step(tb, mo, xt, t, nz, px, False, *(clamp or (None, None)))
+        np.testing.assert_allclose(x0p.cpu().numpy(), ref0.numpy(), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-6, atol=1e-6)
+    tg, o = torch.randn(B, D, generator=g), torch.randn(B, D, generator=g)
+    mse, tgd, od_ = torch.empty(B, device=DEV), tg.to(DEV), o.to(DEV)
+    L.check(L.lib().gpt_mse_rows(L.ptr(tgd), L.ptr(od_), L.ptr(mse), B, D, L.stream()), "mse")
+    np.testing.assert_allclose(mse.cpu().numpy(), ((tg - o) ** 2).mean(1).numpy(), rtol=1e-5)
+
+
+@pytest.mark.parametrize("case,resp,tag,px,clip", [
+    ("mnist_small", "50", "r50", True, False), ("cifar_small", "50", "r50", True, False),
+    ("mnist_small", "50", "r50_eps_clip", False, True), ("mnist_small", "", "full", True, False)])
+def test_p_sample_loop_golden(golden, case, resp, tag, px, clip):
+    """Whole reverse loop in one host call, injected noise, against the reference's trajectory end point."""
+    g = golden(f"g7_sampling_{case}_{tag}")
+    m, plan, sd = build(case, "fp32")
+    m.predict_xstart = px
+    diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=px, noise_schedule="linear", steps=1000,
+                                    timestep_respacing=resp)
+    n = diff.num_timesteps
+    assert n == int(g["num_steps"])
+    B = 3
+    _, _, lt, lp, xp = make_inputs(case, B=B, seed=31)
+    noise = torch.stack([step_noise(1234, i, B, plan.D) for i in range(n)])
+    kw = dict(loss_target=lt.to(DEV), loss_prev=lp.to(DEV), x_prev=xp.to(DEV))
+    got = diff.p_sample_loop(m, (B, plan.D), noise=step_noise(1234, -1, B, plan.D).to(DEV), clip_denoised=clip,
+                             model_kwargs=kw, device="cuda", step_noise=noise)
+    ref = g["sample_at_0"]
+    assert np.abs(got.cpu().numpy() - ref).max() / np.abs(ref).max() < 1e-3
+    if tag == "r50":   # the per-step (progressive) path must agree with the fused loop's structure
+        torch.manual_seed(0)
+        outs = list(diff.p_sample_loop_progressive(m, (B, plan.D), noise=step_noise(1234, -1, B, plan.D).to(DEV),
+                                                   clip_denoised=clip, model_kwargs=kw, device="cuda"))
+        assert len(outs) == n and outs[-1]["sample"].shape == (B, plan.D)
+        assert torch.isfinite(outs[-1]["sample"]).all()
+
+
+def test_p_sample_loop_philox_statistics():
+    """Throughput mode (in-kernel Philox noise): repeatable for a seed, and N(0,1) to sampling error."""
+    n = 1 << 20
+    a, b = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    L.check(L.lib().gpt_randn(L.ptr(a), n, 7, 3, L.stream()), "randn")
+    L.check(L.lib().gpt_randn(L.ptr(b), n, 7, 3, L.stream()), "randn")
+    assert torch.equal(a, b)
+    L.check(L.lib().gpt_randn(L.ptr(b), n, 7, 4, L.stream()), "randn")
+    assert not torch.equal(a, b)
+    assert abs(float(a.mean())) < 5e-3 and abs(float(a.std()) - 1) < 5e-3
+    assert abs(float((a ** 4).mean()) - 3) < 0.1 and abs(float((a * b).mean())) < 5e-3
+
+
+def test_sampling_properties_full_size():
+    """Full-size MNIST model, bf16: rows are independent (sharding by rows changes nothing) and the fused
+    loop equals the per-step path fed the same noise."""
+    m, plan, sd = build("mnist", "bf16", seed=1)
+    diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000,
+                                    timestep_respacing="4")
+    B, n = 6, diff.num_timesteps
+    _, _, lt, lp, xp = (v.to(DEV) for v in make_inputs("mnist", B=B, seed=9))
+    noise = torch.stack([step_noise(99, i, B, plan.D) for i in range(n)]).to(DEV)
+    start = step_noise(99, -1, B, plan.D).to(DEV)
+    kw = dict(loss_target=lt, loss_prev=lp, x_prev=xp)
+    full = diff.p_sample_loop(m, (B, plan.D), noise=start, clip_denoised=False, model_kwargs=kw, step_noise=noise)
+    half = diff.p_sample_loop(m, (3, plan.D), noise=start[:3], clip_denoised=False, step_noise=noise[:, :3].contiguous(),
+                              model_kwargs=dict(loss_target=lt[:3], loss_prev=lp[:3], x_prev=xp[:3]))
+    assert torch.equal(full[:3], half)
+    x = start.clone()
+    tmap = torch.tensor(diff.timestep_map, device=DEV)
+    for i in reversed(range(n)):
+        t = torch.full((B,), i, device=DEV, dtype=torch.long)
+        with torch.no_grad():
+            out = m(x, tmap[t], lt, loss_prev=lp, x_prev=xp)
+        x, _ = diff._posterior(out, x, noise[i].contiguous(), t, None)
+    assert torch.equal(full, x)
+
+
+# ------------------------------------------------------------------------------------------ permutation
+def test_permutation_maps_bit_exact(golden):
+    g = golden("g8_permute")
+    P = gpt_amd.permute
+    for arch, key, draw, idx in ((P.MLP_ARCH, "mlp", op.draw_mlp, op.mlp_index), (P.CNN_ARCH, "cnn", op.draw_cnn, op.cnn_index)):
+        perms = P.draw_permutations(arch, range(16))
+        index = P.build_index(arch, perms, DEV).cpu().numpy()
+        assert index.dtype == np.int64
+        assert np.array_equal(index, g[key].astype(np.int64))
+        assert np.array_equal(index[5], idx(*draw(5)))
+        D = index.shape[1]
+        gen = torch.Generator().manual_seed(1)
+        a, b = torch.randn(16, D, generator=gen), torch.randn(16, D, generator=gen)
+        pa, pb = P.random_permute_batch([a.to(DEV), b.to(DEV)], arch, range(16))
+        ia = torch.from_numpy(index)
+        assert torch.equal(pa.cpu(), torch.gather(a, 1, ia)) and torch.equal(pb.cpu(), torch.gather(b, 1, ia))
