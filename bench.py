@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py - throughput of the G.pt denoiser hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W [--mode sample|train] [--dtype bf16|fp32] [--batch B]
+
+A "step" (sample mode, the default) is ONE reverse-diffusion step of the DDPM p_sample_loop over one batch
+of B parameter vectors per GPU: denoiser forward + in-kernel Philox noise + fused posterior update, inputs
+resident in HBM.  Workload (BASELINE.json configs[1]): the pretrained `mnist_loss` G.pt shapes
+(D = 7960, n_embd 1536, 16 heads, 12 layers, 26 tokens), random-initialised weights, synthetic inputs
+of SURVEY.md section 8(d), B = 320 per GPU (the reference's evaluation batch, 16 nets x 20 prompts).
+`value` = sampled parameter vectors per second under the full 1000-step sampler = B_total / (1000 x step time).
+Rows are independent, so for N > 1 every rank samples its own B rows with no traffic (weak scaling) and the
+ranks exchange only the final gather of the sampled vectors.
+
+One JSON line is printed by rank 0.  Extra objects: `roofline` (the dominant kernel = the MFMA GEMM,
+timed with HIP events recorded on its own stream in a second, instrumented pass of the same steps) and
+`cpu_baseline` (the oracle - a CPU restatement of the reference's PyTorch path - timed on the host cores
+on a bounded sample, rank 0 at N = 1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import gpt_amd                                   # noqa: E402
+from gpt_amd import _lib as L                    # noqa: E402
+from gpt_amd import dp                           # noqa: E402
+from tests.cases import CASES, gpt_kwargs        # noqa: E402
+
+PEAK = {"bf16": 2500.0, "fp32": 157.3}          # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def flops_per_forward(case):
+    """Algorithmic FLOPs per sample per denoiser forward."""
+    c = CASES[case]
+    d, Lr, T, D = c["n_embd"], c["n_layer"], 26, sum(c["parameter_sizes"])
+    return 2 * T * Lr * 12 * d * d + 4 * Lr * T * T * d + 2 * d * (2 * D + 4 * 257) + 2 * d * D
+
+
+def make_model(case, dtype, device, seed=0):
+    torch.manual_seed(seed)
+    m = gpt_amd.Gpt(**gpt_kwargs(case))
+    with torch.no_grad():                                    # the reference zero-inits these (identity model)
+        m.decoder.pos_emb.normal_(0, 0.02)
+        for p in m.decoder.output_parameter_projections:
+            p[0].weight.normal_(0, 0.02)
+    return m.to(device).eval().set_compute_dtype(dtype)
+
+
+def synth_inputs(case, B, device, seed):
+    c = CASES[case]
+    D = sum(c["parameter_sizes"])
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x_prev = (torch.randn(B, D, generator=g) * c["w_std"]).to(device)
+    loss_prev = (c["loss_lo"] + (c["loss_hi"] - c["loss_lo"]) * torch.rand(B, generator=g)).to(device)
+    loss_target = torch.full((B,), float(c["loss_target"]), device=device)
+    start = torch.randn(B, D, generator=g).to(device)
+    return start, loss_target, loss_prev, x_prev
+
+
+class SampleRunner:
+    """Drives gpt_sample_loop over arbitrary step counts (wrapping around the 1000-step schedule)."""
+
+    def __init__(self, model, diff, B, inputs, device):
+        self.m, self.diff, self.B, self.dev = model, diff, B, device
+        self.x, self.lt, self.lp, self.xp = inputs
+        self.eng = model.engine(device)
+        self.ws = self.eng.workspace(B)
+        n = diff.num_timesteps
+        self.tmap = (C.c_int64 * n)(*diff.timestep_map)
+        self.t_model = torch.empty(B, dtype=torch.long, device=device)
+        self.t_index = torch.empty(B, dtype=torch.long, device=device)
+        self.model_out = torch.empty_like(self.x)
+        self.noise = torch.empty_like(self.x)
+        self.coef = diff.coef_table(device)
+        self.cursor = n - 1
+
+    def run(self, steps):
+        n = self.diff.num_timesteps
+        while steps > 0:
+            k = min(steps, self.cursor + 1)
+            first, last = self.cursor, self.cursor - k + 1
+            L.check(L.lib().gpt_sample_loop(
+                C.byref(self.eng.cmodel), C.byref(self.ws), L.ptr(self.x), L.ptr(self.lt), L.ptr(self.lp), 0,
+                L.ptr(self.xp), L.ptr(self.coef), self.tmap, n, first, last, 1, 0, 0.0, 0.0, None, 1234,
+                L.ptr(self.t_model), L.ptr(self.t_index), L.ptr(self.model_out), L.ptr(self.noise), self.B,
+                L.stream()), "gpt_sample_loop")
+            steps -= k
+            self.cursor = last - 1 if last > 0 else n - 1
+
+
+def cpu_baseline(case, seconds_target=20.0):
+    """The oracle's denoising step (forward + posterior update) on the host cores, bounded sample."""
+    from oracle import denoiser as od, diffusion as odf
+    c = CASES[case]
+    torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "64"))))
+    plan = od.Plan(c["parameter_sizes"], 128, 14, True, c["n_head"], c["n_embd"], c["n_layer"], c["chunk_size"],
+                   c["split_policy"], True)
+    sd = od.random_state_dict(plan, seed=0)
+    tb = odf.Tables(1000)
+    B = 16
+    g = torch.Generator().manual_seed(1)
+    x, xp = torch.randn(B, plan.D, generator=g), torch.randn(B, plan.D, generator=g) * 0.538
+    lt, lp = torch.zeros(B), 0.3 + 2.1 * torch.rand(B, generator=g)
+    nz = torch.randn(B, plan.D, generator=g)
+
+    def step(i):
+        t = torch.full((B,), i, dtype=torch.long)
+        with torch.no_grad():
+            out = od.forward(sd, plan, x, t, lt, lp, xp)
+            return odf.posterior_step(tb, out, x, t, nz)[0]
+
+    step(999)
+    t0 = time.perf_counter()
+    step(998)
+    one = time.perf_counter() - t0
+    reps = max(2, min(12, int(seconds_target / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    for i in range(reps):
+        x = step(997 - i)
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": B / dt / 1000.0, "unit": "vectors/s (1000-step DDPM, extrapolated from timed steps)",
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} denoising steps of the CPU oracle (PyTorch fp32) at B={B}, {case} shapes; "
+                      f"{B / dt:.1f} sample-steps/s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--mode", default="sample", choices=["sample", "train"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--case", default="mnist", choices=["mnist", "cifar"])
+    ap.add_argument("--batch", type=int, default=None, help="rows per GPU (default 320 sample / 128 train)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    if args.mode == "train":
+        from gpt_amd.trainstep import bench_train
+        line = bench_train(args, device, world, rank)
+    else:
+        line = bench_sample(args, device, world, rank)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def sync_all(world):
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def bench_sample(args, device, world, rank):
+    case, B = args.case, args.batch or 320
+    model = make_model(case, args.dtype, device)
+    diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
+    runner = SampleRunner(model, diff, B, synth_inputs(case, B, device, seed=100 + rank), device)
+    D = model.D
+
+    runner.run(args.warmup)
+    sync_all(world)
+    t0 = time.perf_counter()
+    runner.run(args.steps)
+    local_rows = runner.x
+    if world > 1:                                             # the only traffic: final gather of the samples
+        local_rows = dp.gather_rows(runner.x, B * world)
+    sync_all(world)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert local_rows.shape == (B * world, D) and bool(torch.isfinite(runner.x).all())
+    ms_per_step = elapsed * 1e3 / args.steps
+    vectors_per_s = B * world / (ms_per_step * 1e-3 * diff.num_timesteps)
+    fwd_flops = flops_per_forward(case) * B
+    line = {
+        "metric": "sampled param-vectors/sec (DDPM)", "value": vectors_per_s, "unit": "vectors/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{case}_loss G.pt shapes (D={D}, n_embd={CASES[case]['n_embd']}, 12 layers, 26 tokens), "
+                               f"1000-step DDPM p_sample_loop, B={B} vectors per GPU, random-init weights, "
+                               f"in-kernel Philox noise; step = 1 reverse-diffusion step",
+                   "batch_per_gpu": B, "diffusion_steps": diff.num_timesteps},
+        "denoiser_tflops_per_gpu": fwd_flops / (ms_per_step * 1e-3) / 1e12,
+    }
+    if not args.no_roofline:
+        lib = L.lib()
+        sync_all(world)
+        L.check(lib.gpt_gemm_prof_enable(1), "prof")
+        runner.run(min(args.steps, 40))
+        torch.cuda.synchronize()
+        ms, fl, nl = C.c_double(), C.c_double(), C.c_int()
+        L.check(lib.gpt_gemm_prof_collect(C.byref(ms), C.byref(fl), C.byref(nl)), "prof")
+        L.check(lib.gpt_gemm_prof_enable(0), "prof")
+        achieved = fl.value / (ms.value * 1e-3) / 1e12
+        line["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK[args.dtype], "unit": "TFLOP/s",
+                            "frac": achieved / PEAK[args.dtype], "traffic": None,
+                            "kernel": "gemm_nt_kernel (qkv/proj/fc1/fc2 contractions)", "launches": nl.value,
+                            "avg_launch_us": ms.value * 1e3 / max(nl.value, 1),
+                            "flops_per_launch": fl.value / max(nl.value, 1)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(case)
+    return line
+
+
+if __name__ == "__main__":
+    main()

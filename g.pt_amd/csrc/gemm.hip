@@ -160,10 +160,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs<T> g) {
   }
 }
 
+// Optional per-launch timing with HIP events recorded on the launch stream (bench.py's roofline pass).
+struct GemmProf {
+  bool on = false;
+  int n = 0;
+  static constexpr int CAP = 4096;
+  hipEvent_t ev[CAP][2];
+  double flops[CAP];
+  bool made = false;
+} g_prof;
+
 template <typename T, int EPI>
 int launch(const GemmArgs<T>& g, hipStream_t s) {
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  const bool rec = g_prof.on && g_prof.n < GemmProf::CAP;
+  if (rec) (void)hipEventRecord(g_prof.ev[g_prof.n][0], s);
   hipLaunchKernelGGL((gemm_nt_kernel<T, EPI>), dim3(tiles), dim3(NTHREADS), 0, s, g);
+  if (rec) {
+    (void)hipEventRecord(g_prof.ev[g_prof.n][1], s);
+    g_prof.flops[g_prof.n++] = 2.0 * g.M * g.N * g.K;
+  }
   return gpt_launch_status("gpt_gemm_nt");
 }
 
@@ -183,6 +199,35 @@ int dispatch(const GemmArgs<T>& g, int epi, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int gpt_gemm_prof_enable(int on) {
+  if (on && !g_prof.made) {
+    for (int i = 0; i < GemmProf::CAP; ++i)
+      for (int j = 0; j < 2; ++j)
+        if (hipEventCreate(&g_prof.ev[i][j]) != hipSuccess) {
+          gpt_set_error("gpt_gemm_prof_enable: hipEventCreate failed");
+          return -1;
+        }
+    g_prof.made = true;
+  }
+  g_prof.on = on != 0;
+  if (on) g_prof.n = 0;
+  return 0;
+}
+
+extern "C" int gpt_gemm_prof_collect(double* total_ms, double* total_flops, int* launches) {
+  GPT_REQUIRE(total_ms && total_flops && launches, "gpt_gemm_prof_collect: null output");
+  double ms = 0, fl = 0;
+  for (int i = 0; i < g_prof.n; ++i) {
+    if (hipEventSynchronize(g_prof.ev[i][1]) != hipSuccess) { gpt_set_error("gpt_gemm_prof_collect: sync failed"); return -1; }
+    float t = 0;
+    if (hipEventElapsedTime(&t, g_prof.ev[i][0], g_prof.ev[i][1]) != hipSuccess) { gpt_set_error("gpt_gemm_prof_collect: elapsed failed"); return -1; }
+    ms += t;
+    fl += g_prof.flops[i];
+  }
+  *total_ms = ms; *total_flops = fl; *launches = g_prof.n;
+  return 0;
+}
 
 extern "C" int gpt_gemm_nt(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                            void* C, int64_t ldc, void* aux, int64_t ldaux, int M, int N, int K, int epilogue,

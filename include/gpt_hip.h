@@ -45,6 +45,13 @@ int gpt_gemm_nt(int dtype, const void* A, int64_t lda, const void* W, int64_t ld
                 void* C, int64_t ldc, void* aux, int64_t ldaux, int M, int N, int K, int epilogue,
                 void* stream);
 
+/* Measurement aid (bench.py roofline pass; no counterpart in the reference): while enabled, every gpt_gemm_nt
+ * launch is bracketed by two HIP events recorded on its own stream (at most 4096 launches per enable);
+ * collect waits for them and returns the summed kernel time, the summed algorithmic FLOPs (2 M N K) and the
+ * launch count.  Not for use under graph capture. */
+int gpt_gemm_prof_enable(int on);
+int gpt_gemm_prof_collect(double* total_ms, double* total_flops, int* launches);
+
 /* y[rows, d](out_dtype) = LayerNorm(x[rows, d] fp32; gamma, beta fp32, eps) (+ add[(row % add_rows), d] fp32).
  * out_dtype: GPT_F32 or GPT_BF16.  Optionally writes mean/rstd (fp32, per row) for the backward.
  * Replaces nn.LayerNorm at transformer.py:70-71 (ln1, ln2), :226 (ln_in, fused with the pos_emb add of
