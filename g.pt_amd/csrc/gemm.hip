@@ -4,45 +4,50 @@
 // denoiser FLOPs).  Both operands are K-contiguous, which is the
 // natural MFMA operand order, so nn.Linear's (out,in) weight layout is consumed as stored.
 //
-// Tile: 128 x 128 per 256-thread workgroup (4 waves as 2 x 2, 64 x 64 each = 2 x 2 MFMA 32x32 tiles),
-// K-step = 128 bytes of K per row (64 bf16 / 32 fp32), so the LDS image and the staging code are the
-// same for both dtypes.  Operands are staged global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per
-// wave-instruction, lane-linear destination) into a double buffer; the bank-conflict swizzle is applied
-// on the per-lane SOURCE address and again on the ds_read_b128 address (phys chunk = chunk ^ ((row>>1)&7),
-// conflict-free for the 16-lane groups of ds_read_b128 on 128-byte rows).
-#include "common.h"
+// One template, two tile shapes (same staging / fragment / epilogue code):
+//   big   256 x 128 per 512-thread workgroup (8 waves as 4 x 2), used when it yields >= 1 workgroup per CU;
+//   small 128 x 128 per 256-thread workgroup (4 waves as 2 x 2), for small problems.
+// Every wave owns a 64 x 64 output = 2 x 2 MFMA 32x32 tiles.  A K-step stages 64 BYTES of K per row
+// (32 bf16 / 16 fp32), so the LDS image and the staging code are identical for both dtypes.
+//
+// Pipeline: a ring of LDS stages filled by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction,
+// lane-linear destination, per-lane source).  The DMA of K-tile t+NSTAGE-1 is issued right after the barrier
+// that opens K-tile t and stays in flight across the following barriers: each wave waits with a COUNTED
+// s_waitcnt vmcnt(n) (only its own pieces of the tiles still ahead may be pending) and a raw s_barrier -
+// __syncthreads() would drain the DMA queue with vmcnt(0).  One barrier per K-tile.
+// LDS per workgroup is 72 KiB (big, 3 stages) / 64 KiB (small, 4 stages): TWO workgroups are resident per CU,
+// so one workgroup's epilogue (global stores, residual read-modify-write) overlaps the other's main loop.
+//
+// Bank conflicts: 64-byte LDS rows; the 16-byte chunk c of row r is stored at chunk c ^ ((r >> 2) & 3) (applied
+// on the per-lane DMA SOURCE address and again on the ds_read_b128 address): conflict-free for the
+// 16-lane groups of ds_read_b128.
+//
+// Epilogue: each wave passes its accumulators through a private 4 KiB LDS patch, 32 x 32 at a time, so
+// that global accesses are 16-byte (fp32) / 8-byte (bf16) row vectors; no workgroup barrier is involved.
+#include "gemm_common.h"
+#include <stdlib.h>
+
+namespace gemmk {
+GemmProf g_prof;
+int gemm256_bf16(const GemmArgs<bf16_t>& g, int epi, hipStream_t s);  // gemm256.hip
+int gemm256_f32(const GemmArgs<float>& g, int epi, hipStream_t s);
+}
 
 namespace {
+using namespace gemmk;
 
-constexpr int BM = 128, BN = 128, ROWB = 128;           // tile rows / cols, bytes of K per staged row
-constexpr int TILE_BYTES = BM * ROWB;                   // 16 KiB per operand per buffer
-constexpr int NTHREADS = 256;
+constexpr int ROWB = 64;  // bytes of K per staged row
 
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-template <typename T>
-struct GemmArgs {
-  const T* A;
-  const T* W;
-  const float* bias;
-  void* C;
-  void* aux;
-  int64_t lda, ldw, ldc, ldaux;
-  int M, N, K;
-};
-
-// stage one 128-row x 128-byte operand tile: 16 pieces of 1 KiB, 4 per wave
-template <typename T>
-__device__ __forceinline__ void stage_tile(const T* __restrict__ base, int64_t ld, int row0, int nrows_total, int k0,
-                                           char* lds_tile, int wid, int lane) {
+// LDS-DMA of NP 1-KiB pieces (16 rows x 64 B each) of an operand panel
+template <typename T, int NP>
+__device__ __forceinline__ void stage_rows(const T* __restrict__ base, int64_t ld, int row0, int nrows_total, int k0,
+                                           char* lds_tile, int first_piece, int lane) {
   constexpr int EPC = 16 / sizeof(T);  // elements per 16-byte chunk
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int piece = wid * 4 + i;
-    const int rr = piece * 8 + (lane >> 3);
-    const int pc = lane & 7;
-    const int lc = pc ^ ((rr >> 1) & 7);
+  for (int i = 0; i < NP; ++i) {
+    const int piece = first_piece + i;
+    const int rr = piece * 16 + (lane >> 2);
+    const int lc = (lane & 3) ^ ((rr >> 2) & 3);
     int grow = row0 + rr;
     grow = grow < nrows_total ? grow : nrows_total - 1;  // clamp: rows past the edge are computed and dropped
     const T* src = base + (int64_t)grow * ld + k0 + lc * EPC;
@@ -51,13 +56,18 @@ __device__ __forceinline__ void stage_tile(const T* __restrict__ base, int64_t l
 }
 
 __device__ __forceinline__ u32x4 read_frag(const char* lds_tile, int row, int lc) {
-  const int off = row * ROWB + ((lc ^ ((row >> 1) & 7)) << 4);
+  const int off = row * ROWB + ((lc ^ ((row >> 2) & 3)) << 4);
   return *reinterpret_cast<const u32x4*>(lds_tile + off);
 }
 
-template <typename T, int EPI>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs<T> g) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [buf][A|W]
+// WM x 2 waves of 64 x 64; BM = 64 * WM, BN = 128
+template <typename T, int EPI, int WM, int NSTAGE>
+__global__ __launch_bounds__(WM * 128, WM) void gemm_nt_kernel(GemmArgs<T> g) {
+  constexpr int BM = 64 * WM, BN = 128, NWAVES = WM * 2;
+  constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+  constexpr int PIECES_A = BM / 16 / NWAVES, PIECES_W = BN / 16 / NWAVES;  // per wave: 2 + 1 (big), 2 + 2 (small)
+  constexpr int DMA_PER_TILE = PIECES_A + PIECES_W;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 1, wc = wid & 1;
@@ -82,22 +92,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs<T> g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  stage_tile<T>(g.A, g.lda, m0, g.M, 0, smem, wid, lane);
-  stage_tile<T>(g.W, g.ldw, n0, g.N, 0, smem + TILE_BYTES, wid, lane);
-  __syncthreads();
+  auto stage = [&](int kt) {
+    char* buf = smem + (kt % NSTAGE) * STAGE_BYTES;
+    stage_rows<T, PIECES_A>(g.A, g.lda, m0, g.M, kt * BK, buf, wid * PIECES_A, lane);
+    stage_rows<T, PIECES_W>(g.W, g.ldw, n0, g.N, kt * BK, buf + BM * ROWB, wid * PIECES_W, lane);
+  };
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) stage(s);
 
   const int fr = lane & 31, fh = lane >> 5;
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    char* bufA = smem + cur * 2 * TILE_BYTES;
-    char* bufW = bufA + TILE_BYTES;
-    if (kt + 1 < nk) {
-      char* nA = smem + (cur ^ 1) * 2 * TILE_BYTES;
-      stage_tile<T>(g.A, g.lda, m0, g.M, (kt + 1) * BK, nA, wid, lane);
-      stage_tile<T>(g.W, g.ldw, n0, g.N, (kt + 1) * BK, nA + TILE_BYTES, wid, lane);
-    }
+    // K-tile kt has landed once at most the pieces of the tiles issued after it are pending
+    const int ahead = nk - 1 - kt < NSTAGE - 2 ? nk - 1 - kt : NSTAGE - 2;
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_TILE) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_TILE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + NSTAGE - 1 < nk) stage(kt + NSTAGE - 1);
+    const char* bufA = smem + (kt % NSTAGE) * STAGE_BYTES;
+    const char* bufW = bufA + BM * ROWB;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < 2; ++ks) {
       u32x4 a[2], b[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) a[i] = read_frag(bufA, wr * 64 + i * 32 + fr, 2 * ks + fh);
@@ -119,63 +135,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GemmArgs<T> g) {
           }
         }
     }
-    __syncthreads();
   }
+  __syncthreads();  // every wave is done reading the last stage before the epilogue patches overwrite LDS
 
-  // epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wc * 64 + j * 32 + fr;
-    if (n >= g.N) continue;
-    const float bv = g.bias ? g.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        if (m >= g.M) continue;
-        float v = acc[i][j][e] + bv;
-        const int64_t ci = (int64_t)m * g.ldc + n;
-        if constexpr (EPI == GPT_EPI_STORE) {
-          elem<T>::store((T*)g.C + ci, v);
-        } else if constexpr (EPI == GPT_EPI_GELU) {
-          elem<T>::store((T*)g.C + ci, gelu_erf(v));
-        } else if constexpr (EPI == GPT_EPI_RESADD) {
-          const float res = g.aux ? ((const float*)g.aux)[(int64_t)m * g.ldaux + n] : ((const float*)g.C)[ci];
-          ((float*)g.C)[ci] = res + v;
-        } else if constexpr (EPI == GPT_EPI_STORE_F32) {
-          ((float*)g.C)[ci] = v;
-        } else if constexpr (EPI == GPT_EPI_GELU_AUX) {
-          elem<T>::store((T*)g.aux + (int64_t)m * g.ldaux + n, v);
-          elem<T>::store((T*)g.C + ci, gelu_erf(v));
-        } else if constexpr (EPI == GPT_EPI_DGELU) {
-          const float pre = elem<T>::load((const T*)g.aux + (int64_t)m * g.ldaux + n);
-          elem<T>::store((T*)g.C + ci, v * gelu_erf_grad(pre));
-        } else if constexpr (EPI == GPT_EPI_ACCUM_F32) {
-          float* c = (float*)g.C + ci;
-          *c = *c + v;
-        }
-      }
-    }
-  }
+  // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  float* patch = reinterpret_cast<float*>(smem + wid * PATCH_BYTES);
+  epilogue_wave<T, EPI, 2>(g, acc, patch, m0 + wr * 64, n0 + wc * 64, lane);
 }
 
-// Optional per-launch timing with HIP events recorded on the launch stream (bench.py's roofline pass).
-struct GemmProf {
-  bool on = false;
-  int n = 0;
-  static constexpr int CAP = 4096;
-  hipEvent_t ev[CAP][2];
-  double flops[CAP];
-  bool made = false;
-} g_prof;
 
-template <typename T, int EPI>
-int launch(const GemmArgs<T>& g, hipStream_t s) {
+template <typename T, int EPI, int WM, int NSTAGE>
+int launch_shape(const GemmArgs<T>& g, hipStream_t s) {
+  constexpr int BM = 64 * WM, BN = 128;
+  constexpr int LDS = NSTAGE * (BM + BN) * ROWB;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EPI, WM, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LDS) != hipSuccess) {
+      gpt_set_error("gpt_gemm_nt: cannot reserve %d bytes of LDS", LDS);
+      return -1;
+    }
+    attr_set = true;
+  }
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
   const bool rec = g_prof.on && g_prof.n < GemmProf::CAP;
   if (rec) (void)hipEventRecord(g_prof.ev[g_prof.n][0], s);
-  hipLaunchKernelGGL((gemm_nt_kernel<T, EPI>), dim3(tiles), dim3(NTHREADS), 0, s, g);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, WM, NSTAGE>), dim3(tiles), dim3(WM * 128), LDS, s, g);
   if (rec) {
     (void)hipEventRecord(g_prof.ev[g_prof.n][1], s);
     g_prof.flops[g_prof.n++] = 2.0 * g.M * g.N * g.K;
@@ -183,8 +168,32 @@ int launch(const GemmArgs<T>& g, hipStream_t s) {
   return gpt_launch_status("gpt_gemm_nt");
 }
 
+template <typename T, int EPI>
+int launch(const GemmArgs<T>& g, hipStream_t s) {
+  static int mode = [] {
+    const char* e = getenv("GPT_GEMM_TILE");  // 0 = auto, 1 = 128 x 128, 2 = 256 x 128 (experiments)
+    return e ? atoi(e) : 0;
+  }();
+  const int tiles_big = ((g.M + 255) / 256) * ((g.N + 127) / 128);
+  const bool big = mode == 2 || (mode == 0 && tiles_big >= 256);
+  return big ? launch_shape<T, EPI, 4, 3>(g, s) : launch_shape<T, EPI, 2, 4>(g, s);
+}
+
+int tile_mode() {
+  static int mode = [] {
+    const char* e = getenv("GPT_GEMM_TILE");  // 0 = auto, 1 = 128 x 128, 2 = 256 x 128, 3 = 256 x 256 (experiments)
+    return e ? atoi(e) : 0;
+  }();
+  return mode;
+}
+
 template <typename T>
 int dispatch(const GemmArgs<T>& g, int epi, hipStream_t s) {
+  const int tiles256 = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+  if (tile_mode() == 3 || (tile_mode() == 0 && tiles256 >= 128)) {
+    if constexpr (sizeof(T) == 2) return gemm256_bf16(g, epi, s);
+    else return gemm256_f32(g, epi, s);
+  }
   switch (epi) {
     case GPT_EPI_STORE: return launch<T, GPT_EPI_STORE>(g, s);
     case GPT_EPI_GELU: return launch<T, GPT_EPI_GELU>(g, s);
@@ -241,6 +250,9 @@ extern "C" int gpt_gemm_nt(int dtype, const void* A, int64_t lda, const void* W,
   GPT_REQUIRE((lda * esz) % 16 == 0 && (ldw * esz) % 16 == 0, "gpt_gemm_nt: rows must be 16-byte aligned");
   GPT_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, "gpt_gemm_nt: operands must be 16-byte aligned");
   GPT_REQUIRE(A && W && C, "gpt_gemm_nt: null operand");
+  GPT_REQUIRE(N % 8 == 0 && ldc % 4 == 0 && ((uintptr_t)C % 16) == 0 && ((uintptr_t)bias % 16) == 0,
+              "gpt_gemm_nt: N must be a multiple of 8, ldc of 4, C and bias 16-byte aligned (vector epilogue)");
+  GPT_REQUIRE(!aux || (ldaux % 4 == 0 && ((uintptr_t)aux % 16) == 0), "gpt_gemm_nt: aux must be 16-byte aligned, ldaux %% 4 == 0");
   if (epilogue == GPT_EPI_GELU_AUX || epilogue == GPT_EPI_DGELU)
     GPT_REQUIRE(aux && ldaux >= N, "gpt_gemm_nt: epilogue %d needs aux with ldaux >= N", epilogue);
   hipStream_t s = (hipStream_t)stream;

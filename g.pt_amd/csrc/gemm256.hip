@@ -1,0 +1,232 @@
+// 256 x 256 block-tile MFMA GEMM for gfx950 (the large-problem path of gpt_gemm_nt).
+//
+// 8 waves (2 x 4), each owning 128 x 64 of the output = 4 x 2 MFMA 32x32 tiles (128 accumulator registers).
+// K-tile = 128 bytes of K per row (64 bf16 / 32 fp32).  LDS = 2 K-tile buffers x 64 KiB, each buffer split
+// into FOUR 16-KiB half-tiles: A-h0 / A-h1 hold the first / second 64 rows of every wave-row's 128,
+// W-h0 / W-h1 the first / second 32 columns of every wave-column's 64.  A K-tile is consumed in four phases,
+// one 64 x 32 quadrant of the wave tile each (8 MFMAs):
+//     p0: (A-h0, W-h0)   p1: (A-h0, W-h1)   p2: (A-h1, W-h1)   p3: (A-h1, W-h0, from registers)
+// so a half-tile slot is free again after ONE phase, and the LDS-DMA that refills it (for K-tile t+2, same
+// buffer) is issued in the very next phase: p1: A-h0(t+2), p2: W-h0(t+2), p3: W-h1(t+2), p0': A-h1(t+2).
+// Every DMA therefore has 6-7 phases (about 1.5 K-tiles of MFMA work) to land, with only two buffers.
+// Waits are COUNTED: before the reads of p0/p1/p2 a wave waits s_waitcnt vmcnt(10) - the five half-tiles
+// issued after the one it needs (2 DMA instructions each) may still be in flight - then a raw s_barrier
+// (a __syncthreads() would drain the DMA queue).  The last two K-tiles drain with vmcnt(0).
+// WAR safety: a slot read in phase p is refilled after the barrier that opens phase p+1, which every wave
+// reaches only after its own phase-p reads have returned (lgkmcnt(0) before its MFMAs).
+//
+// Operand traffic per FLOP is half that of a 128 x 128 tile (L2 -> LDS is the scarce resource here: a CU's
+// vector-memory path moves 64 B/clk), LDS reads per MFMA 0.75 instead of 1, DMA instructions per MFMA 0.25
+// instead of 0.5.  One workgroup per CU (128 KiB LDS).
+#include "gemm_common.h"
+
+namespace gemmk {
+namespace {
+
+constexpr int RB = 128;             // bytes of K per LDS row
+constexpr int HALF = 128 * RB;      // 16 KiB half-tile: 128 LDS rows
+constexpr int BUF = 4 * HALF;       // A-h0 | A-h1 | W-h0 | W-h1
+constexpr int LDS_BYTES = 2 * BUF;  // 128 KiB
+
+// 128-byte rows: chunk c of LDS row r lives at chunk c ^ ((r >> 1) & 7): conflict-free ds_read_b128
+__device__ __forceinline__ u32x4 frag(const char* half, int row, int lc) {
+  return *reinterpret_cast<const u32x4*>(half + row * RB + ((lc ^ ((row >> 1) & 7)) << 4));
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int tiles_n = (g.N + 255) / 256;
+  const int m0 = (swz / tiles_n) * 256, n0 = (swz % tiles_n) * 256;
+
+  constexpr int BK = RB / sizeof(T);
+  constexpr int EPC = 16 / sizeof(T);
+  const int nk = g.K / BK;
+
+  // per-lane DMA source rows: this wave fills LDS rows [wid*16, wid*16+16) of every half-tile (2 pieces of 8 rows)
+  const T* srcA[2][2];  // [half][piece]
+  const T* srcW[2][2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int lr = wid * 16 + p * 8 + (lane >> 3);
+    const int lc = (lane & 7) ^ ((lr >> 1) & 7);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int gm = m0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
+      gm = gm < g.M ? gm : g.M - 1;
+      srcA[h][p] = g.A + (int64_t)gm * g.lda + lc * EPC;
+      int gn = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
+      gn = gn < g.N ? gn : g.N - 1;
+      srcW[h][p] = g.W + (int64_t)gn * g.ldw + lc * EPC;
+    }
+  }
+  auto dma = [&](const T* const (&src)[2], int kt, int slot) {
+    char* dst = smem + (kt & 1) * BUF + slot * HALF + wid * 2048;
+    __builtin_amdgcn_global_load_lds((gptr_t)(src[0] + kt * BK), (lptr_t)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(src[1] + kt * BK), (lptr_t)(dst + 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // prologue: K-tiles 0 and 1 in consumption order
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+    if (t < nk) {
+      dma(srcA[0], t, 0);
+      dma(srcW[0], t, 2);
+      dma(srcW[1], t, 3);
+      dma(srcA[1], t, 1);
+    }
+
+  const int fr = lane & 31, fh = lane >> 5;
+  auto mma = [&](const u32x4 (&a)[2][4], const u32x4 (&b)[4], int i0, int j) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if constexpr (sizeof(T) == 2) {
+          acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i][ks]),
+                                                                  __builtin_bit_cast(bf16x8, b[ks]), acc[i0 + i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[i][ks][e]), __uint_as_float(b[ks][e]),
+                                                                  acc[i0 + i][j], 0, 0, 0);
+        }
+      }
+  };
+  // Two wave groups (wr = 0 / 1: one wave of each on every SIMD) run ONE BARRIER APART: every phase is
+  // {load segment: wait, barrier, ds_reads, DMA issue} barrier {compute segment: 8 MFMAs}, so while one group
+  // multiplies, its SIMD partner reads LDS and issues DMA; the matrix pipe alternates between the two.
+  // Because of the offset a wave retires (vmcnt) the DMA of a half-tile ONE PHASE BEFORE the phase that reads
+  // it: the other group's pieces are then covered by a barrier that group has passed as well.
+#define SEG_WAIT()                                                          \
+  do {                                                                      \
+    if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   \
+  } while (0)
+#define SEG_BARRIER()                        \
+  do {                                       \
+    __builtin_amdgcn_sched_barrier(0);       \
+    __builtin_amdgcn_s_barrier();            \
+    __builtin_amdgcn_sched_barrier(0);       \
+  } while (0)
+#define SEG_READS_DONE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define SEG_COMPUTE(A_, B_, I0, J)           \
+  do {                                       \
+    SEG_BARRIER();                           \
+    __builtin_amdgcn_s_setprio(1);           \
+    mma(A_, B_, I0, J);                      \
+    __builtin_amdgcn_s_setprio(0);           \
+  } while (0)
+
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // A-h0(0), W-h0(0) landed (6 half-tiles issued after them)
+  if (wr == 1) __builtin_amdgcn_s_barrier();           // group 1 runs one barrier behind group 0
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* buf = smem + (kt & 1) * BUF;
+    const bool steady = kt + 2 < nk;
+    u32x4 a[2][4], b0[4], b1[4];
+    // ---- p0: A-h0 x W-h0        (retire W-h1(kt) for p1)
+    SEG_WAIT();
+    SEG_BARRIER();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) b0[ks] = frag(buf + 2 * HALF, wc * 32 + fr, 2 * ks + fh);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a[i][ks] = frag(buf, wr * 64 + i * 32 + fr, 2 * ks + fh);
+    if (kt >= 1 && kt + 1 < nk) dma(srcA[1], kt + 1, 1);   // A-h1(kt+1): its slot was last read in p2(kt-1)
+    SEG_READS_DONE();
+    SEG_COMPUTE(a, b0, 0, 0);
+    // ---- p1: A-h0 x W-h1        (retire A-h1(kt) for p2)
+    SEG_WAIT();
+    SEG_BARRIER();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) b1[ks] = frag(buf + 3 * HALF, wc * 32 + fr, 2 * ks + fh);
+    if (steady) dma(srcA[0], kt + 2, 0);                    // A-h0 slot of this buffer: read in p0
+    SEG_READS_DONE();
+    SEG_COMPUTE(a, b1, 0, 1);
+    // ---- p2: A-h1 x W-h1
+    SEG_BARRIER();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a[i][ks] = frag(buf + HALF, wr * 64 + i * 32 + fr, 2 * ks + fh);
+    if (steady) dma(srcW[0], kt + 2, 2);                    // W-h0 slot: read in p0 (kept in registers)
+    SEG_READS_DONE();
+    SEG_COMPUTE(a, b1, 2, 1);
+    // ---- p3: A-h1 x W-h0, both in registers   (retire A-h0(kt+1), W-h0(kt+1) for the next p0)
+    SEG_WAIT();
+    SEG_BARRIER();
+    if (steady) dma(srcW[1], kt + 2, 3);                    // W-h1 slot: read in p1
+    SEG_COMPUTE(a, b0, 2, 0);
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();            // balance group 1's extra barrier
+#undef SEG_WAIT
+#undef SEG_BARRIER
+#undef SEG_READS_DONE
+#undef SEG_COMPUTE
+  __syncthreads();
+
+  // epilogue through a private 4 KiB LDS patch per wave, 32 x 32 at a time (see gemm.hip)
+  float* patch = reinterpret_cast<float*>(smem + wid * PATCH_BYTES);
+  epilogue_wave<T, EPI, 4>(g, acc, patch, m0 + wr * 128, n0 + wc * 64, lane);
+}
+
+template <typename T, int EPI>
+int launch256(const GemmArgs<T>& g, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm256_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+        hipSuccess) {
+      gpt_set_error("gpt_gemm_nt: cannot reserve %d bytes of LDS", LDS_BYTES);
+      return -1;
+    }
+    attr_set = true;
+  }
+  const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+  const bool rec = g_prof.on && g_prof.n < GemmProf::CAP;
+  if (rec) (void)hipEventRecord(g_prof.ev[g_prof.n][0], s);
+  hipLaunchKernelGGL((gemm256_kernel<T, EPI>), dim3(tiles), dim3(512), LDS_BYTES, s, g);
+  if (rec) {
+    (void)hipEventRecord(g_prof.ev[g_prof.n][1], s);
+    g_prof.flops[g_prof.n++] = 2.0 * g.M * g.N * g.K;
+  }
+  return gpt_launch_status("gpt_gemm_nt");
+}
+
+template <typename T>
+int dispatch256(const GemmArgs<T>& g, int epi, hipStream_t s) {
+  switch (epi) {
+    case GPT_EPI_STORE: return launch256<T, GPT_EPI_STORE>(g, s);
+    case GPT_EPI_GELU: return launch256<T, GPT_EPI_GELU>(g, s);
+    case GPT_EPI_RESADD: return launch256<T, GPT_EPI_RESADD>(g, s);
+    case GPT_EPI_STORE_F32: return launch256<T, GPT_EPI_STORE_F32>(g, s);
+    case GPT_EPI_GELU_AUX: return launch256<T, GPT_EPI_GELU_AUX>(g, s);
+    case GPT_EPI_DGELU: return launch256<T, GPT_EPI_DGELU>(g, s);
+    case GPT_EPI_ACCUM_F32: return launch256<T, GPT_EPI_ACCUM_F32>(g, s);
+  }
+  gpt_set_error("gpt_gemm_nt: unknown epilogue %d", epi);
+  return -1;
+}
+
+}  // namespace
+
+int gemm256_bf16(const GemmArgs<bf16_t>& g, int epi, hipStream_t s) { return dispatch256<bf16_t>(g, epi, s); }
+int gemm256_f32(const GemmArgs<float>& g, int epi, hipStream_t s) { return dispatch256<float>(g, epi, s); }
+
+}  // namespace gemmk

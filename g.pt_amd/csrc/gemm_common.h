@@ -1,0 +1,199 @@
+// Shared pieces of the MFMA GEMM kernels (gemm.hip: 64-row wave tiles; gemm256.hip: 256 x 256 block tile).
+#pragma once
+#include "common.h"
+
+namespace gemmk {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <typename T>
+struct GemmArgs {
+  const T* A;
+  const T* W;
+  const float* bias;
+  void* C;
+  void* aux;
+  int64_t lda, ldw, ldc, ldaux;
+  int M, N, K;
+};
+
+template <typename T>
+__device__ __forceinline__ void store4(T* p, const float4& v) {
+  if constexpr (sizeof(T) == 4) {
+    *reinterpret_cast<float4*>(p) = v;
+  } else {
+    uint2 o;
+    o.x = pack_bf16x2(v.x, v.y);
+    o.y = pack_bf16x2(v.z, v.w);
+    *reinterpret_cast<uint2*>(p) = o;
+  }
+}
+template <typename T>
+__device__ __forceinline__ float4 load4(const T* p) {
+  if constexpr (sizeof(T) == 4) {
+    return *reinterpret_cast<const float4*>(p);
+  } else {
+    const uint2 o = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u), __uint_as_float(o.y << 16),
+                       __uint_as_float(o.y & 0xffff0000u));
+  }
+}
+// fp32 mode: libm erff (parity).  bf16 mode: Abramowitz-Stegun 7.1.26 (|erf error| < 1.5e-7, far below bf16's
+// 2^-9 output rounding) = one v_exp + one v_rcp + ~12 VALU instead of erff's ~40.
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * __expf(-z * z);
+  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+template <typename T>
+__device__ __forceinline__ float4 gelu4(const float4& v) {
+  if constexpr (sizeof(T) == 4) return make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+  else return make_float4(gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w));
+}
+
+// one 4-wide row segment of the epilogue (v already holds acc + bias)
+template <typename T, int EPI>
+__device__ __forceinline__ void epi_apply(const GemmArgs<T>& g, int m, int n, const float4& v) {
+  const int64_t ci = (int64_t)m * g.ldc + n;
+  const int64_t ai = (int64_t)m * g.ldaux + n;
+  if constexpr (EPI == GPT_EPI_STORE) {
+    store4<T>((T*)g.C + ci, v);
+  } else if constexpr (EPI == GPT_EPI_GELU) {
+    store4<T>((T*)g.C + ci, gelu4<T>(v));
+  } else if constexpr (EPI == GPT_EPI_RESADD) {
+    const float4 r = g.aux ? *reinterpret_cast<const float4*>((const float*)g.aux + ai)
+                           : *reinterpret_cast<const float4*>((const float*)g.C + ci);
+    *reinterpret_cast<float4*>((float*)g.C + ci) = make_float4(r.x + v.x, r.y + v.y, r.z + v.z, r.w + v.w);
+  } else if constexpr (EPI == GPT_EPI_STORE_F32) {
+    *reinterpret_cast<float4*>((float*)g.C + ci) = v;
+  } else if constexpr (EPI == GPT_EPI_GELU_AUX) {
+    store4<T>((T*)g.aux + ai, v);
+    store4<T>((T*)g.C + ci, gelu4<T>(v));
+  } else if constexpr (EPI == GPT_EPI_DGELU) {
+    const float4 pre = load4<T>((const T*)g.aux + ai);
+    store4<T>((T*)g.C + ci, make_float4(v.x * gelu_erf_grad(pre.x), v.y * gelu_erf_grad(pre.y),
+                                         v.z * gelu_erf_grad(pre.z), v.w * gelu_erf_grad(pre.w)));
+  } else if constexpr (EPI == GPT_EPI_ACCUM_F32) {
+    float4* c = reinterpret_cast<float4*>((float*)g.C + ci);
+    const float4 r = *c;
+    *c = make_float4(r.x + v.x, r.y + v.y, r.z + v.z, r.w + v.w);
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Wave-level epilogue shared by the kernels.  A wave owns NI x 2 MFMA 32x32 accumulator tiles = (32 NI) x 64
+// outputs.  32 rows at a time go through a PRIVATE LDS patch [32][68] fp32 (8.5 KiB, padded pitch: the
+// 16-byte row reads are conflict-free), after which each lane holds 8 consecutive columns of one row:
+// bf16 outputs leave as ONE 16-byte store per lane and every row of the wave's 64 columns is written as a
+// full 128-byte line (fp32: 256 bytes = two lines).  Only the wave itself touches its patch: no workgroup
+// barrier.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+constexpr int PATCH_PITCH = 68;
+constexpr int PATCH_BYTES = 32 * PATCH_PITCH * 4;
+
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const float4& a, const float4& b) {
+  if constexpr (sizeof(T) == 4) {
+    reinterpret_cast<float4*>(p)[0] = a;
+    reinterpret_cast<float4*>(p)[1] = b;
+  } else {
+    uint4 o;
+    o.x = pack_bf16x2(a.x, a.y); o.y = pack_bf16x2(a.z, a.w);
+    o.z = pack_bf16x2(b.x, b.y); o.w = pack_bf16x2(b.z, b.w);
+    *reinterpret_cast<uint4*>(p) = o;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float4& a, float4& b) {
+  if constexpr (sizeof(T) == 4) {
+    a = reinterpret_cast<const float4*>(p)[0];
+    b = reinterpret_cast<const float4*>(p)[1];
+  } else {
+    const uint4 o = *reinterpret_cast<const uint4*>(p);
+    a = make_float4(__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u), __uint_as_float(o.y << 16), __uint_as_float(o.y & 0xffff0000u));
+    b = make_float4(__uint_as_float(o.z << 16), __uint_as_float(o.z & 0xffff0000u), __uint_as_float(o.w << 16), __uint_as_float(o.w & 0xffff0000u));
+  }
+}
+__device__ __forceinline__ float4 add4(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 dgelu4(const float4& v, const float4& pre) {
+  return make_float4(v.x * gelu_erf_grad(pre.x), v.y * gelu_erf_grad(pre.y), v.z * gelu_erf_grad(pre.z), v.w * gelu_erf_grad(pre.w));
+}
+
+// 8 consecutive columns of row m starting at column n (n % 8 == 0; the caller checked m < M, n < N; N % 8 == 0)
+template <typename T, int EPI>
+__device__ __forceinline__ void epi_apply8(const GemmArgs<T>& g, int m, int n, const float4& a, const float4& b) {
+  const int64_t ci = (int64_t)m * g.ldc + n;
+  const int64_t ai = (int64_t)m * g.ldaux + n;
+  if constexpr (EPI == GPT_EPI_STORE) {
+    store8<T>((T*)g.C + ci, a, b);
+  } else if constexpr (EPI == GPT_EPI_GELU) {
+    store8<T>((T*)g.C + ci, gelu4<T>(a), gelu4<T>(b));
+  } else if constexpr (EPI == GPT_EPI_RESADD) {
+    const float* rp = g.aux ? (const float*)g.aux + ai : (const float*)g.C + ci;
+    const float4 r0 = reinterpret_cast<const float4*>(rp)[0], r1 = reinterpret_cast<const float4*>(rp)[1];
+    store8<float>((float*)g.C + ci, add4(r0, a), add4(r1, b));
+  } else if constexpr (EPI == GPT_EPI_STORE_F32) {
+    store8<float>((float*)g.C + ci, a, b);
+  } else if constexpr (EPI == GPT_EPI_GELU_AUX) {
+    store8<T>((T*)g.aux + ai, a, b);
+    store8<T>((T*)g.C + ci, gelu4<T>(a), gelu4<T>(b));
+  } else if constexpr (EPI == GPT_EPI_DGELU) {
+    float4 p0, p1;
+    load8<T>((const T*)g.aux + ai, p0, p1);
+    store8<T>((T*)g.C + ci, dgelu4(a, p0), dgelu4(b, p1));
+  } else if constexpr (EPI == GPT_EPI_ACCUM_F32) {
+    float* c = (float*)g.C + ci;
+    const float4 r0 = reinterpret_cast<const float4*>(c)[0], r1 = reinterpret_cast<const float4*>(c)[1];
+    store8<float>(c, add4(r0, a), add4(r1, b));
+  }
+}
+
+template <typename T, int EPI, int NI>
+__device__ __forceinline__ void epilogue_wave(const GemmArgs<T>& g, const f32x16 (&acc)[NI][2], float* patch, int mrow0,
+                                              int ncol0, int lane) {
+  const int fr = lane & 31, fh = lane >> 5;
+  const int pr = lane >> 3, pc8 = (lane & 7) * 8;
+  const int n = ncol0 + pc8;
+  float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+  if (g.bias && n < g.N) {
+    b0 = reinterpret_cast<const float4*>(g.bias + n)[0];
+    b1 = reinterpret_cast<const float4*>(g.bias + n)[1];
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + 4 * fh) * PATCH_PITCH + j * 32 + fr] = acc[i][j][e];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = p * 8 + pr;
+      const int m = mrow0 + i * 32 + row;
+      const float4 v0 = *reinterpret_cast<const float4*>(patch + row * PATCH_PITCH + pc8);
+      const float4 v1 = *reinterpret_cast<const float4*>(patch + row * PATCH_PITCH + pc8 + 4);
+      if (m < g.M && n < g.N) epi_apply8<T, EPI>(g, m, n, add4(v0, b0), add4(v1, b1));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+// Optional per-launch timing with HIP events recorded on the launch stream (bench.py roofline pass).
+struct GemmProf {
+  bool on = false;
+  int n = 0;
+  static constexpr int CAP = 4096;
+  hipEvent_t ev[CAP][2];
+  double flops[CAP];
+  bool made = false;
+};
+extern GemmProf g_prof;
+
+}  // namespace gemmk

@@ -39,7 +39,9 @@ const char* gpt_last_error(void);
 int gpt_abi_version(void);
 
 /* C[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N]).  A, W: `dtype`, row-major, leading dims lda/ldw in
- * elements, K % 64 == 0 (bf16) or K % 32 == 0 (fp32), 16-byte aligned rows.  bias: fp32 or NULL.
+ * elements, K % 64 == 0 (bf16) or K % 32 == 0 (fp32), 16-byte aligned rows; N % 8 == 0, ldc % 4 == 0, C/aux/bias
+ * 16-byte aligned (vector epilogue).  bias: fp32 or NULL.  In bf16 mode GELU uses a 1.5e-7-accurate erf
+ * polynomial (far below bf16 output rounding); fp32 mode uses erff.
  * Replaces nn.Linear on the path: Gpt/models/transformer.py:38-40 (q,k,v), :50 (proj), :63-65 (mlp). */
 int gpt_gemm_nt(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                 void* C, int64_t ldc, void* aux, int64_t ldaux, int M, int N, int K, int epilogue,
