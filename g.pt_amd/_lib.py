@@ -33,6 +33,18 @@ class Model(C.Structure):
                 ("layers", C.POINTER(Layer))]
 
 
+class LayerGrad(C.Structure):
+    _fields_ = [(n, vp) for n in ("wqkv_t", "wproj_t", "w1_t", "w2_t", "g_ln1_w", "g_ln1_b", "g_ln2_w", "g_ln2_b",
+                                  "g_wqkv", "g_bqkv", "g_wproj", "g_bproj", "g_w1", "g_b1", "g_w2", "g_b2")]
+
+
+class Backward(C.Structure):
+    _fields_ = [("layers", C.POINTER(LayerGrad))] + \
+               [(n, vp) for n in ("g_pos_emb", "g_ln_in_w", "g_ln_in_b", "g_ln_f_w", "g_ln_f_b")] + \
+               [("g_enc_w", vp * MAX_TOKENS), ("g_dec_w", vp * MAX_TOKENS)] + \
+               [(n, vp) for n in ("g", "gt", "d_h", "d_qkv", "d_act", "tA", "tB", "d_tok")]
+
+
 class Workspace(C.Structure):
     _fields_ = [("B_max", i32), ("layer_stride", i32)] + \
                [(n, vp) for n in ("scal", "enc", "x", "h1", "qkv", "att", "h2", "pre", "act", "hf", "stats")]
@@ -58,11 +70,16 @@ _PROTOS = {
     "gpt_fill_i64": ([vp, i64, i64, vp], i32),
     "gpt_f32_to_bf16": ([vp, vp, i64, vp], i32),
     "gpt_bf16_to_f32": ([vp, vp, i64, vp], i32),
-    "gpt_transpose": ([i32, vp, vp, i32, i32, vp], i32),
+    "gpt_transpose": ([i32, vp, vp, i32, i32, i64, vp], i32),
+    "gpt_layernorm_bwd": ([vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp], i32),
+    "gpt_attention_bwd": ([i32, vp, vp, vp, i32, i32, i32, i32, vp], i32),
+    "gpt_colsum": ([i32, vp, i64, vp, i32, i32, vp], i32),
+    "gpt_small_gemm": ([i32, vp, i64, i64, i32, vp, i64, i64, vp, i64, i32, i32, i32, i32, vp], i32),
     "gpt_perm_index_mlp": ([vp, vp, i32, i32, i32, i32, vp], i32),
     "gpt_perm_index_cnn": ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "gpt_perm_gather": ([C.POINTER(vp), C.POINTER(vp), i32, vp, i32, i32, vp], i32),
     "gpt_denoiser_forward": ([C.POINTER(Model), C.POINTER(Workspace), vp, vp, vp, vp, i32, vp, vp, i32, vp], i32),
+    "gpt_denoiser_backward": ([C.POINTER(Model), C.POINTER(Workspace), C.POINTER(Backward), vp, vp, vp, i32, vp], i32),
     "gpt_sample_loop": ([C.POINTER(Model), C.POINTER(Workspace), vp, vp, vp, i32, vp, vp, C.POINTER(i64), i32, i32,
                          i32, i32, i32, f32, f32, vp, u64, vp, vp, vp, vp, i32, vp], i32),
 }

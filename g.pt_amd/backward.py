@@ -1,0 +1,190 @@
+"""Training path of the denoiser: forward with kept activations + hand-written backward (gpt_denoiser_backward),
+bridged to torch.autograd so `diffusion.training_losses(model, ...)["loss"].backward()` (main.py:47-67) works
+unchanged, also under DistributedDataParallel.
+
+Gradients are produced into ONE flat fp32 arena; each parameter's gradient is a view of it (the query / key /
+value weight gradients of a layer are three consecutive slices of the fused [3d, d] gradient the kernels write).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+class GradArena:
+    """Flat fp32 gradient buffer + the C descriptor that points the kernels at its slices."""
+
+    def __init__(self, model, device):
+        dec = model.decoder
+        d, Lr = dec.n_embd, dec.n_layer
+        self.slices = {}                      # parameter name -> (offset, numel)
+        off = 0
+
+        def take(name, numel):
+            nonlocal off
+            self.slices[name] = (off, numel)
+            off += (numel + 3) // 4 * 4       # keep every slice 16-byte aligned
+            return self.slices[name][0]
+
+        self.layer_off = []
+        for l in range(Lr):
+            p = f"decoder.blocks.{l}."
+            lo = {}
+            # fused [3d, d] weight / [3d] bias gradients: query | key | value back to back (no padding between them)
+            lo["g_wqkv"] = off
+            for nm in ("query", "key", "value"):
+                self.slices[p + f"attn.{nm}.weight"] = (off, d * d)
+                off += d * d
+            lo["g_bqkv"] = off
+            for nm in ("query", "key", "value"):
+                self.slices[p + f"attn.{nm}.bias"] = (off, d)
+                off += d
+            off = (off + 3) // 4 * 4
+            lo["g_wproj"] = take(p + "attn.proj.weight", d * d)
+            lo["g_bproj"] = take(p + "attn.proj.bias", d)
+            lo["g_w1"] = take(p + "mlp.0.weight", 4 * d * d)
+            lo["g_b1"] = take(p + "mlp.0.bias", 4 * d)
+            lo["g_w2"] = take(p + "mlp.2.weight", 4 * d * d)
+            lo["g_b2"] = take(p + "mlp.2.bias", d)
+            for ln in ("ln1", "ln2"):
+                lo[f"g_{ln}_w"] = take(p + ln + ".weight", d)
+                lo[f"g_{ln}_b"] = take(p + ln + ".bias", d)
+            self.layer_off.append(lo)
+        self.glob = {"g_pos_emb": take("decoder.pos_emb", dec.block_size * d)}
+        for ln, key in (("ln_in", "g_ln_in"), ("ln_f", "g_ln_f")):
+            self.glob[key + "_w"] = take(f"decoder.{ln}.weight", d)
+            self.glob[key + "_b"] = take(f"decoder.{ln}.bias", d)
+        self.enc_off = [take(f"decoder.input_parameter_projections.{i}.0.weight", d * k)
+                        for i, k in enumerate(dec.input_splits)]
+        self.dec_off = [take(f"decoder.output_parameter_projections.{j}.0.weight", n * d)
+                        for j, n in enumerate(dec.output_splits)]
+        self.numel = off
+        self.device = device
+        self.names = [n for n, _ in model.named_parameters()]
+        assert set(self.names) == set(self.slices), set(self.names) ^ set(self.slices)
+
+    def new_buffer(self):
+        return torch.zeros(self.numel, dtype=torch.float32, device=self.device)
+
+    def views(self, buf, model):
+        out = []
+        for name, p in model.named_parameters():
+            o, n = self.slices[name]
+            out.append(buf[o:o + n].view_as(p))
+        return out
+
+
+def _ensure_training_state(eng):
+    """Transposed packed weights (dgrad operands) + backward scratch, refreshed with the packed weights."""
+    m, dec = eng.model, eng.model.decoder
+    if getattr(eng, "_t_sig", None) == eng.sig and getattr(eng, "arena", None) is not None:
+        return
+    lib = L.lib()
+    if getattr(eng, "arena", None) is None:
+        eng.arena = GradArena(m, eng.device)
+    keep = []
+    eng.wt = []
+    for l in range(dec.n_layer):
+        ly = eng.cmodel.layers[l]
+        d = dec.n_embd
+        ts = {}
+        for key, ptr, rows, cols in (("wqkv_t", ly.wqkv, 3 * d, d), ("wproj_t", ly.wproj, d, d), ("w1_t", ly.w1, 4 * d, d),
+                                     ("w2_t", ly.w2, d, 4 * d)):
+            t = torch.empty(cols, rows, dtype=eng.tdtype, device=eng.device)
+            L.check(lib.gpt_transpose(eng.code, ptr, L.ptr(t), rows, cols, rows, L.stream()), "gpt_transpose")
+            ts[key] = t
+        eng.wt.append(ts)
+    eng._t_sig = eng.sig
+
+
+def _scratch(eng, B):
+    have = getattr(eng, "_bw_scratch", None)
+    if have is not None and have[0] >= B:
+        return have[1]
+    dec = eng.model.decoder
+    d, T = dec.n_embd, dec.block_size
+    M = B * T
+    Mp = (M + 63) // 64 * 64
+    dev, td = eng.device, eng.tdtype
+    s = dict(g=torch.empty(M, d, dtype=torch.float32, device=dev), gt=torch.empty(M, d, dtype=td, device=dev),
+             d_h=torch.empty(M, d, dtype=td, device=dev), d_qkv=torch.empty(M, 3 * d, dtype=td, device=dev),
+             d_act=torch.empty(M, 4 * d, dtype=td, device=dev), tA=torch.empty(4 * d, Mp, dtype=td, device=dev),
+             tB=torch.empty(4 * d, Mp, dtype=td, device=dev), d_tok=torch.empty(M, d, dtype=torch.float32, device=dev))
+    eng._bw_scratch = (B, s)
+    return s
+
+
+def _descriptor(eng, buf, scratch):
+    dec = eng.model.decoder
+    ar = eng.arena
+    base = buf.data_ptr()
+    layers = (L.LayerGrad * dec.n_layer)()
+    for l in range(dec.n_layer):
+        lg = layers[l]
+        for k, t in eng.wt[l].items():
+            setattr(lg, k, L.ptr(t))
+        for k, o in ar.layer_off[l].items():
+            setattr(lg, k, base + 4 * o)
+    bw = L.Backward()
+    bw.layers = C.cast(layers, C.POINTER(L.LayerGrad))
+    for k, o in ar.glob.items():
+        setattr(bw, k, base + 4 * o)
+    for i, o in enumerate(ar.enc_off):
+        bw.g_enc_w[i] = base + 4 * o
+    for j, o in enumerate(ar.dec_off):
+        bw.g_dec_w[j] = base + 4 * o
+    for k, t in scratch.items():
+        setattr(bw, k, L.ptr(t))
+    return bw, layers
+
+
+def forward_keep(model, x, t, lt, lp, x_prev):
+    """Training forward: keeps per-layer activations and LayerNorm statistics in the engine's workspace."""
+    eng = model.engine(x.device)
+    _ensure_training_state(eng)
+    B = x.shape[0]
+    ws = eng.workspace(B, keep_activations=True)
+    out = torch.empty_like(x)
+    L.check(L.lib().gpt_denoiser_forward(C.byref(eng.cmodel), C.byref(ws), L.ptr(x), L.ptr(t), L.ptr(lt), L.ptr(lp),
+                                         int(lt.dtype == torch.float64), L.ptr(x_prev), L.ptr(out), B, L.stream()),
+            "gpt_denoiser_forward")
+    return eng, ws, out
+
+
+def backward_into(eng, ws, x, x_prev, d_out, buf):
+    """Runs the backward of the last forward_keep on this engine, accumulating into the flat buffer `buf`."""
+    B = x.shape[0]
+    scratch = _scratch(eng, B)
+    bw, keep = _descriptor(eng, buf, scratch)
+    L.check(L.lib().gpt_denoiser_backward(C.byref(eng.cmodel), C.byref(ws), C.byref(bw), L.ptr(x), L.ptr(x_prev),
+                                          L.ptr(d_out), B, L.stream()), "gpt_denoiser_backward")
+    del keep
+
+
+class DenoiseFunction(torch.autograd.Function):
+    """autograd node of one denoiser call.  The parameters are explicit inputs so that their AccumulateGrad
+    nodes (and DistributedDataParallel's hooks on them) receive the gradients."""
+
+    @staticmethod
+    def forward(ctx, model, x, t, lt, lp, x_prev, *params):
+        eng, ws, out = forward_keep(model, x, t, lt, lp, x_prev)
+        ctx.model, ctx.eng, ctx.ws = model, eng, ws
+        ctx.save_for_backward(x, x_prev)
+        ctx.sig = eng.sig
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, x_prev = ctx.saved_tensors
+        eng = ctx.eng
+        if eng.sig != ctx.sig:
+            raise RuntimeError("G.pt parameters changed between forward and backward")
+        buf = eng.arena.new_buffer()
+        backward_into(eng, ctx.ws, x, x_prev, d_out.detach().float().contiguous(), buf)
+        grads = eng.arena.views(buf, ctx.model)
+        return (None, None, None, None, None, None, *grads)
+
+    @staticmethod
+    def run(model, x, t, lt, lp, x_prev):
+        return DenoiseFunction.apply(model, x, t, lt, lp, x_prev, *model.parameters())

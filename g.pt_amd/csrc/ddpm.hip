@@ -172,20 +172,21 @@ __global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* __restri
     dst[i] = bf16_to_f32(src[i]);
 }
 
-// 64 x 64 tile transpose through padded LDS
+// 64 x 64 tile transpose through padded LDS; dst[c][r], r in [rows, ld_dst) zero-filled
 template <typename T>
-__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int rows, int cols) {
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int rows, int cols,
+                                                        int64_t ld_dst) {
   __shared__ T tile[64][65];
   const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int i = ty; i < 64; i += 4) {
     const int r = r0 + i, c = c0 + tx;
-    if (r < rows && c < cols) tile[i][tx] = src[(int64_t)r * cols + c];
+    tile[i][tx] = (r < rows && c < cols) ? src[(int64_t)r * cols + c] : (T)0;
   }
   __syncthreads();
   for (int i = ty; i < 64; i += 4) {
     const int c = c0 + i, r = r0 + tx;
-    if (r < rows && c < cols) dst[(int64_t)c * rows + r] = tile[tx][i];
+    if (r < ld_dst && c < cols) dst[(int64_t)c * ld_dst + r] = tile[tx][i];
   }
 }
 
@@ -276,13 +277,13 @@ extern "C" int gpt_bf16_to_f32(const void* src, float* dst, int64_t n, void* str
   return gpt_launch_status("gpt_bf16_to_f32");
 }
 
-extern "C" int gpt_transpose(int dtype, const void* src, void* dst, int rows, int cols, void* stream) {
+extern "C" int gpt_transpose(int dtype, const void* src, void* dst, int rows, int cols, int64_t ld_dst, void* stream) {
   GPT_REQUIRE(dtype == GPT_F32 || dtype == GPT_BF16, "gpt_transpose: bad dtype %d", dtype);
-  GPT_REQUIRE(src && dst && rows > 0 && cols > 0, "gpt_transpose: bad arguments");
-  const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  GPT_REQUIRE(src && dst && rows > 0 && cols > 0 && ld_dst >= rows, "gpt_transpose: bad arguments");
+  const dim3 grid((cols + 63) / 64, (int)((ld_dst + 63) / 64));
   if (dtype == GPT_BF16)
-    hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, rows, cols);
+    hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, rows, cols, ld_dst);
   else
-    hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, (float*)dst, rows, cols);
+    hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, (float*)dst, rows, cols, ld_dst);
   return gpt_launch_status("gpt_transpose");
 }

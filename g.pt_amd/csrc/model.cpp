@@ -112,3 +112,84 @@ extern "C" int gpt_sample_loop(const gpt_model_t* m, const gpt_workspace_t* ws, 
   }
   return 0;
 }
+
+extern "C" int gpt_denoiser_backward(const gpt_model_t* m, const gpt_workspace_t* ws, const gpt_backward_t* bw,
+                                     const float* x, const float* x_prev, const float* d_out, int B, void* stream) {
+  CHECK(validate(m, ws, B, "gpt_denoiser_backward"));
+  GPT_REQUIRE(bw && bw->layers && x && x_prev && d_out, "gpt_denoiser_backward: null operand");
+  GPT_REQUIRE(ws->layer_stride == 1, "gpt_denoiser_backward: needs the workspace of a training forward");
+  const int d = m->d, T = m->T, M = B * T, L = m->n_layer, dt = m->dtype;
+  const size_t es = esize(dt);
+  const size_t Mmax = (size_t)ws->B_max * T;
+  const int64_t Mp = ((int64_t)M + 63) / 64 * 64;
+  const int W = 2 * m->nfreq + 1;
+  hipStream_t hs = (hipStream_t)stream;
+  auto xbuf = [&](int idx) { return ws->x + (size_t)idx * Mmax * d; };
+  auto lay = [&](void* base, int l, size_t width) { return (void*)((char*)base + (size_t)l * Mmax * width * es); };
+  auto stat = [&](int idx, int which) { return ws->stats + ((size_t)idx * 2 + which) * Mmax; };
+  // dW[n_out, k_in] += dY^T . X through the NT kernel: both operands transposed to [*, Mp] (K = rows, zero padded)
+  auto wgrad = [&](const void* dY, int n_out, const void* X, int k_in, float* gW) -> int {
+    CHECK(gpt_transpose(dt, dY, bw->tA, M, n_out, Mp, stream));
+    CHECK(gpt_transpose(dt, X, bw->tB, M, k_in, Mp, stream));
+    return gpt_gemm_nt(dt, bw->tA, Mp, bw->tB, Mp, nullptr, gW, k_in, nullptr, 0, n_out, k_in, (int)Mp, GPT_EPI_ACCUM_F32, stream);
+  };
+
+  // decoder: d_tok[b, j, :] = d_out[b, off_j..] . W_j   (zero for the tokens that are not decoded);  dW_j += d_out_j^T . hf_j
+  if (hipMemsetAsync(bw->d_tok, 0, (size_t)M * d * sizeof(float), hs) != hipSuccess) { gpt_set_error("memset failed"); return -1; }
+  for (int j = 0; j < m->n_out_tok; ++j) {
+    const float* dj = d_out + m->dec_off[j];
+    CHECK(gpt_small_gemm(GPT_F32, dj, m->D, 1, dt, m->dec_w[j], d, 1, bw->d_tok + (size_t)j * d, (int64_t)T * d, B, d, m->dec_n[j], 0, stream));
+    CHECK(gpt_small_gemm(GPT_F32, dj, 1, m->D, dt, (const char*)ws->hf + (size_t)j * d * es, (int64_t)T * d, 1, bw->g_dec_w[j], d,
+                         m->dec_n[j], d, B, 1, stream));
+  }
+  CHECK(gpt_layernorm_bwd(bw->d_tok, GPT_F32, xbuf(2 * L), stat(2 * L + 1, 0), stat(2 * L + 1, 1), m->ln_f_w, nullptr, bw->g, bw->gt, dt,
+                          bw->g_ln_f_w, bw->g_ln_f_b, M, d, stream));
+
+  for (int l = L - 1; l >= 0; --l) {
+    const gpt_layer_t& ly = m->layers[l];
+    const gpt_layer_grad_t& gl = bw->layers[l];
+    const void* h1 = lay(ws->h1, l, d);
+    const void* qkv = lay(ws->qkv, l, 3 * (size_t)d);
+    const void* att = lay(ws->att, l, d);
+    const void* h2 = lay(ws->h2, l, d);
+    const void* act = lay(ws->act, l, 4 * (size_t)d);
+    void* pre = lay(ws->pre, l, 4 * (size_t)d);
+    // mlp.2
+    CHECK(gpt_colsum(dt, bw->gt, d, gl.g_b2, M, d, stream));
+    CHECK(wgrad(bw->gt, d, act, 4 * d, gl.g_w2));
+    CHECK(gpt_gemm_nt(dt, bw->gt, d, gl.w2_t, d, nullptr, bw->d_act, 4 * d, pre, 4 * d, M, 4 * d, d, GPT_EPI_DGELU, stream));
+    // mlp.0
+    CHECK(gpt_colsum(dt, bw->d_act, 4 * d, gl.g_b1, M, 4 * d, stream));
+    CHECK(wgrad(bw->d_act, 4 * d, h2, d, gl.g_w1));
+    CHECK(gpt_gemm_nt(dt, bw->d_act, 4 * d, gl.w1_t, 4 * d, nullptr, bw->d_h, d, nullptr, 0, M, d, 4 * d, GPT_EPI_STORE, stream));
+    CHECK(gpt_layernorm_bwd(bw->d_h, dt, xbuf(2 * l + 1), stat(2 + 2 * l, 0), stat(2 + 2 * l, 1), ly.ln2_w, bw->g, bw->g, bw->gt, dt,
+                            gl.g_ln2_w, gl.g_ln2_b, M, d, stream));
+    // attention output projection
+    CHECK(gpt_colsum(dt, bw->gt, d, gl.g_bproj, M, d, stream));
+    CHECK(wgrad(bw->gt, d, att, d, gl.g_wproj));
+    CHECK(gpt_gemm_nt(dt, bw->gt, d, gl.wproj_t, d, nullptr, bw->d_h, d, nullptr, 0, M, d, d, GPT_EPI_STORE, stream));
+    CHECK(gpt_attention_bwd(dt, qkv, bw->d_h, bw->d_qkv, B, T, m->n_head, d / m->n_head, stream));
+    // query | key | value
+    CHECK(gpt_colsum(dt, bw->d_qkv, 3 * d, gl.g_bqkv, M, 3 * d, stream));
+    CHECK(wgrad(bw->d_qkv, 3 * d, h1, d, gl.g_wqkv));
+    CHECK(gpt_gemm_nt(dt, bw->d_qkv, 3 * d, gl.wqkv_t, 3 * d, nullptr, bw->d_h, d, nullptr, 0, M, d, 3 * d, GPT_EPI_STORE, stream));
+    CHECK(gpt_layernorm_bwd(bw->d_h, dt, xbuf(2 * l), stat(1 + 2 * l, 0), stat(1 + 2 * l, 1), ly.ln1_w, bw->g, bw->g, bw->gt, dt,
+                            gl.g_ln1_w, gl.g_ln1_b, M, d, stream));
+  }
+  // position embedding: sum over the batch of the gradient of x0 = ln_in(enc) + pos_emb
+  CHECK(gpt_colsum(GPT_F32, bw->g, (int64_t)T * d, bw->g_pos_emb, B, T * d, stream));
+  CHECK(gpt_layernorm_bwd(bw->g, GPT_F32, ws->enc, stat(0, 0), stat(0, 1), m->ln_in_w, nullptr, bw->d_tok, nullptr, GPT_F32,
+                          bw->g_ln_in_w, bw->g_ln_in_b, M, d, stream));
+  for (int i = 0; i < T; ++i) {
+    const float* src;
+    int64_t src_ld;
+    switch (m->enc_src[i]) {
+      case GPT_SRC_X: src = x + m->enc_off[i]; src_ld = m->D; break;
+      case GPT_SRC_XPREV: src = x_prev + m->enc_off[i]; src_ld = m->D; break;
+      default: src = ws->scal + m->enc_off[i]; src_ld = (int64_t)m->n_scalar * W; break;
+    }
+    CHECK(gpt_small_gemm(GPT_F32, bw->d_tok + (size_t)i * d, 1, (int64_t)T * d, GPT_F32, src, src_ld, 1, bw->g_enc_w[i], m->enc_k[i],
+                         d, m->enc_k[i], B, 1, stream));
+  }
+  return 0;
+}

@@ -130,8 +130,26 @@ int gpt_fill_i64(int64_t* out, int64_t n, int64_t value, void* stream);
 /* dtype conversion helpers (packed bf16 weight copies; round-to-nearest-even). */
 int gpt_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int gpt_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
-/* dst[c, r] = src[r, c]  for a row-major [rows, cols] matrix of `dtype`. */
-int gpt_transpose(int dtype, const void* src, void* dst, int rows, int cols, void* stream);
+/* dst[c, r] = src[r, c]  for a row-major [rows, cols] matrix of `dtype`; dst rows have leading dimension
+ * ld_dst >= rows and columns [rows, ld_dst) are written as zero (K padding of the wgrad GEMM operands). */
+int gpt_transpose(int dtype, const void* src, void* dst, int rows, int cols, int64_t ld_dst, void* stream);
+
+/* ---- backward kernels (what autograd derives for transformer.py:34-72, 215-242 in the reference) ----
+ * LayerNorm backward: gout[rows,d] (fp32) = (resid ? resid : 0) + dLN/dx(dy); gout_t: optional copy in gout_t_dtype;
+ * dgamma/dbeta (fp32 [d]) are ACCUMULATED (atomics).  dy: dy_dtype [rows,d]; x fp32; mean/rstd from the forward. */
+int gpt_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd,
+                      const float* gamma, const float* resid, float* gout, void* gout_t, int gout_t_dtype,
+                      float* dgamma, float* dbeta, int rows, int d, void* stream);
+/* dqkv[B*T,3d] from qkv[B*T,3d] and dy[B*T,d] (gradient of the attention output), all `dtype`. */
+int gpt_attention_bwd(int dtype, const void* qkv, const void* dy, void* dqkv, int B, int T, int n_head, int hd,
+                      void* stream);
+/* out[c] += sum_r X[r, c]  (bias and position-embedding gradients; atomics). */
+int gpt_colsum(int dtype, const void* X, int64_t ld, float* out, int rows, int cols, void* stream);
+/* C[m,n] (+)= sum_k A[m*a_sm + k*a_sk] * B[k*b_sk + n*b_sn], fp32 FMA, arbitrary strides (ragged encoder /
+ * decoder gradients). */
+int gpt_small_gemm(int a_dtype, const void* A, int64_t a_sm, int64_t a_sk, int b_dtype, const void* B,
+                   int64_t b_sk, int64_t b_sn, float* C, int64_t ldc, int M, int N, int K, int accumulate,
+                   void* stream);
 
 /* Permutation augmentation (Gpt/data/augment.py:25-75 with data_gen/train_mnist.py:28-50 and
  * data_gen/train_cifar10.py:27-47).  perms: int32 device array [n_samples, perm_len] holding, per sample,
@@ -194,6 +212,34 @@ typedef struct {
   void* hf;        /* (dtype) [M, d]       ln_f output                               */
   float* stats;    /* fp32 [(2 L + 2)][2][M]  LayerNorm mean / rstd (stride mode only, else NULL) */
 } gpt_workspace_t;
+
+/* Gradient outputs and scratch of gpt_denoiser_backward.  Every g_* is fp32 in the parameter's own layout and
+ * is ACCUMULATED into (the caller zeroes them): g_wqkv is [3d, d] = the query | key | value weight gradients
+ * back to back (the host makes the three .grad tensors views of it). */
+typedef struct {
+  const void *wqkv_t, *wproj_t, *w1_t, *w2_t;   /* (dtype) transposed weights [d,3d] [d,d] [d,4d] [4d,d] for dgrad */
+  float *g_ln1_w, *g_ln1_b, *g_ln2_w, *g_ln2_b, *g_wqkv, *g_bqkv, *g_wproj, *g_bproj, *g_w1, *g_b1, *g_w2, *g_b2;
+} gpt_layer_grad_t;
+
+typedef struct {
+  const gpt_layer_grad_t* layers;               /* host array [n_layer] */
+  float *g_pos_emb, *g_ln_in_w, *g_ln_in_b, *g_ln_f_w, *g_ln_f_b;
+  float* g_enc_w[GPT_MAX_TOKENS];               /* fp32 [d, k_i] */
+  float* g_dec_w[GPT_MAX_TOKENS];               /* fp32 [n_j, d] */
+  float* g;        /* scratch fp32 [M, d]   residual-stream gradient               */
+  void* gt;        /* scratch (dtype) [M, d]                                         */
+  void* d_h;       /* scratch (dtype) [M, d]                                         */
+  void* d_qkv;     /* scratch (dtype) [M, 3d]                                        */
+  void* d_act;     /* scratch (dtype) [M, 4d]                                        */
+  void* tA;        /* scratch (dtype) [4d, Mp]  transposed operand, Mp = M rounded up to 64 */
+  void* tB;        /* scratch (dtype) [4d, Mp]                                       */
+  float* d_tok;    /* scratch fp32 [M, d]   decoder / encoder token gradients        */
+} gpt_backward_t;
+
+/* Backward of gpt_denoiser_forward run on a layer_stride == 1 workspace: d_out[B, D] = dLoss/d(out).
+ * x / x_prev / t inputs are not differentiated (training_losses needs parameter gradients only). */
+int gpt_denoiser_backward(const gpt_model_t* m, const gpt_workspace_t* ws, const gpt_backward_t* bw, const float* x,
+                          const float* x_prev, const float* d_out, int B, void* stream);
 
 /* out[B, D] = Gpt.forward(x, t, loss_target, loss_prev, x_prev)   (transformer.py:440-464) */
 int gpt_denoiser_forward(const gpt_model_t* m, const gpt_workspace_t* ws, const float* x, const int64_t* t,

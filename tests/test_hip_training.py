@@ -1,0 +1,163 @@
+"""GPU parity tests of the training path: backward kernels against torch autograd (fp64 on the CPU), and
+training_losses + backward + one optimisation step against the fixtures produced by the reference."""
+from copy import deepcopy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import denoiser as od          # noqa: E402
+from tests.cases import CASES, gpt_kwargs, make_inputs, slim  # noqa: E402
+from tests.test_hip_parity import DEV, build, plan_of, rel_err  # noqa: E402
+
+import gpt_amd                              # noqa: E402
+from gpt_amd import _lib as L               # noqa: E402
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("H,hd,T", [(2, 96, 26), (2, 128, 26), (3, 32, 18), (1, 64, 32)])
+def test_attention_backward(dtype, tol, H, hd, T):
+    g = torch.Generator().manual_seed(H * hd + T)
+    B, d = 3, H * hd
+    code = L.dtype_code(dtype)
+    td = L.torch_dtype(code)
+    qkv_d = torch.randn(B * T, 3 * d, generator=g).to(DEV).to(td)
+    dy_d = torch.randn(B * T, d, generator=g).to(DEV).to(td)
+    qkv = qkv_d.float().cpu().double().requires_grad_(True)
+    f = qkv.view(B, T, 3, H, hd)
+    q, k, v = (f[:, :, i].transpose(1, 2) for i in range(3))
+    y = (torch.softmax(q @ k.transpose(-2, -1) / np.sqrt(hd), dim=-1) @ v).transpose(1, 2).reshape(B * T, d)
+    y.backward(dy_d.float().cpu().double())
+    dqkv = torch.empty_like(qkv_d)
+    L.check(L.lib().gpt_attention_bwd(code, L.ptr(qkv_d), L.ptr(dy_d), L.ptr(dqkv), B, T, H, hd, L.stream()), "attention_bwd")
+    assert rel_err(dqkv.float().cpu(), qkv.grad) < tol
+
+
+@pytest.mark.parametrize("d", [192, 1536])
+@pytest.mark.parametrize("dy_dtype", ["fp32", "bf16"])
+def test_layernorm_backward(d, dy_dtype):
+    g = torch.Generator().manual_seed(d)
+    rows = 130
+    x = (torch.randn(rows, d, generator=g) * 2 + 0.3)
+    w = 1 + 0.1 * torch.randn(d, generator=g)
+    resid = torch.randn(rows, d, generator=g)
+    code = L.dtype_code(dy_dtype)
+    dy_d = torch.randn(rows, d, generator=g).to(DEV).to(L.torch_dtype(code))
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    br = torch.zeros(d, dtype=torch.double, requires_grad=True)
+    torch.nn.functional.layer_norm(xr, (d,), wr, br, 1e-5).backward(dy_d.float().cpu().double())
+    xd, wd, rd = x.to(DEV), w.to(DEV), resid.to(DEV)
+    mean = x.mean(1).to(DEV)
+    rstd = (1 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)).to(DEV)
+    gout, gt = torch.empty(rows, d, device=DEV), torch.empty(rows, d, device=DEV, dtype=torch.bfloat16)
+    dg, db = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    L.check(L.lib().gpt_layernorm_bwd(L.ptr(dy_d), code, L.ptr(xd), L.ptr(mean), L.ptr(rstd), L.ptr(wd), L.ptr(rd), L.ptr(gout),
+                                      L.ptr(gt), L.BF16, L.ptr(dg), L.ptr(db), rows, d, L.stream()), "ln_bwd")
+    assert rel_err(gout.cpu() - resid, xr.grad) < 2e-5
+    assert rel_err(gt.float().cpu(), gout.cpu()) < 1e-2
+    assert rel_err(dg.cpu(), wr.grad) < 2e-5 and rel_err(db.cpu(), br.grad) < 2e-5
+
+
+def test_small_gemm_colsum_transpose():
+    g = torch.Generator().manual_seed(4)
+    A, Bm = torch.randn(70, 33, generator=g), torch.randn(33, 90, generator=g)
+    Ad, Bd = A.to(DEV), Bm.t().contiguous().to(DEV).to(torch.bfloat16)     # B stored transposed, bf16
+    Cd = torch.ones(70, 90, device=DEV)
+    L.check(L.lib().gpt_small_gemm(L.F32, L.ptr(Ad), 33, 1, L.BF16, L.ptr(Bd), 1, 33, L.ptr(Cd), 90, 70, 90, 33, 1, L.stream()), "sg")
+    ref = 1 + A.double() @ Bd.float().cpu().t().double()
+    assert rel_err(Cd.cpu(), ref) < 1e-5
+    X = torch.randn(300, 500, generator=g).to(DEV)
+    out = torch.zeros(500, device=DEV)
+    L.check(L.lib().gpt_colsum(L.F32, L.ptr(X), 500, L.ptr(out), 300, 500, L.stream()), "colsum")
+    assert rel_err(out.cpu(), X.cpu().double().sum(0)) < 1e-5
+    Xt = torch.full((500, 320), 7.0, device=DEV)
+    L.check(L.lib().gpt_transpose(L.F32, L.ptr(X), L.ptr(Xt), 300, 500, 320, L.stream()), "transpose")
+    assert torch.equal(Xt[:, :300].cpu(), X.cpu().t()) and float(Xt[:, 300:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("case,tag", [("mnist_small", "x0"), ("mnist_small", "eps"), ("cifar_small", "x0")])
+def test_training_losses_and_grads_golden(golden, case, tag):
+    """diffusion.training_losses(model, ...) + .backward() through the HIP path, fp32, against the reference."""
+    g = golden(f"g6_training_{case}_{tag}")
+    px = tag == "x0"
+    m, plan, sd = build(case, "fp32")
+    m.predict_xstart = px
+    m.train()
+    diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=px, noise_schedule="linear", steps=1000)
+    _, _, lt, lp, xp = make_inputs(case, B=6, seed=21)
+    x_start, t, noise = (torch.from_numpy(g[k]).to(DEV) for k in ("x_start", "t", "noise"))
+    terms = diff.training_losses(m, x_start, t, model_kwargs=dict(loss_target=lt.double().to(DEV), loss_prev=lp.double().to(DEV),
+                                                                  x_prev=xp.to(DEV)), noise=noise)
+    np.testing.assert_allclose(terms["mse"].detach().cpu().numpy(), g["mse"], rtol=2e-4)
+    loss = terms["loss"].mean()
+    assert abs(float(loss) - float(g["loss"])) < 2e-4 * abs(float(g["loss"]))
+    loss.backward()
+    named = dict(m.named_parameters())
+    for k in g.files:
+        if k.startswith("grad::"):
+            got = slim(named[k[6:]].grad.cpu().numpy())
+            assert np.abs(got - g[k]).max() < 1e-3 * np.abs(g[k]).max() + 1e-9, k
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())))
+    assert abs(gn - float(g["grad_norm"])) < 1e-3 * float(g["grad_norm"])
+    assert abs(m.gradient_norm() - gn) < 1e-4 * gn
+
+
+def test_train_step_golden(golden):
+    """loss -> backward -> clip 0.75 -> AdamW (2 groups) -> EMA 0.9999, the sequence of main.py:63-74."""
+    g = golden("g9_trainstep_mnist_small")
+    m, plan, sd = build("mnist_small", "fp32")
+    m.train()
+    ema = deepcopy(m)
+    diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
+    _, _, lt, lp, xp = make_inputs("mnist_small", B=6, seed=41)
+    x_start, t, noise = (torch.from_numpy(g[k]).to(DEV) for k in ("x_start", "t", "noise"))
+    opt = m.configure_optimizers(lr=4e-4, wd=0.1, betas=(0.9, 0.999))
+    terms = diff.training_losses(m, x_start, t, model_kwargs=dict(loss_target=lt.to(DEV), loss_prev=lp.to(DEV), x_prev=xp.to(DEV)),
+                                 noise=noise)
+    loss = (terms["loss"] * torch.ones(6, device=DEV)).mean()
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    total_norm = torch.nn.utils.clip_grad_norm_(m.parameters(), 0.75)
+    opt.step()
+    with torch.no_grad():
+        pe, pm = dict(ema.named_parameters()), dict(m.named_parameters())
+        for k in pe:
+            pe[k].mul_(0.9999).add_(pm[k], alpha=1 - 0.9999)
+    assert abs(float(loss) - float(g["loss"])) < 2e-4 * float(g["loss"])
+    assert abs(float(total_norm) - float(g["total_norm"])) < 1e-3 * float(g["total_norm"])
+    for k in g.files:
+        if k.startswith("param::"):
+            np.testing.assert_allclose(slim(pm[k[7:]].detach().cpu().numpy()), g[k], rtol=0, atol=2e-6, err_msg=k)
+        if k.startswith("ema::"):
+            np.testing.assert_allclose(slim(pe[k[5:]].detach().cpu().numpy()), g[k], rtol=0, atol=2e-6, err_msg=k)
+    # after the step the packed weights must follow the parameters (stale-copy check)
+    with torch.no_grad():
+        x, tt, lt2, lp2, xp2 = (v.to(DEV) for v in make_inputs("mnist_small", B=4, seed=5))
+        out = m(x, tt, lt2, loss_prev=lp2, x_prev=xp2)
+        ref = od.forward({k: v.detach().cpu() for k, v in m.state_dict().items()}, plan, *make_inputs("mnist_small", B=4, seed=5))
+    assert np.abs(out.cpu().numpy() - ref.numpy()).max() / np.abs((ref - xp2.cpu()).numpy()).max() < 2e-4
+
+
+def test_training_bf16_close_to_fp32():
+    m32, plan, sd = build("mnist_small", "fp32", seed=2)
+    m16, _, _ = build("mnist_small", "bf16", seed=2)
+    diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
+    _, _, lt, lp, xp = (v.to(DEV) for v in make_inputs("mnist_small", B=8, seed=3))
+    g = torch.Generator().manual_seed(9)
+    x_start = xp + 0.1 * torch.randn(xp.shape, generator=g).to(DEV)
+    t = torch.randint(0, 1000, (8,), generator=g).to(DEV)
+    noise = torch.randn(xp.shape, generator=g).to(DEV)
+    grads = []
+    for m in (m32, m16):
+        m.train()
+        terms = diff.training_losses(m, x_start, t, model_kwargs=dict(loss_target=lt, loss_prev=lp, x_prev=xp), noise=noise)
+        terms["loss"].mean().backward()
+        grads.append({k: p.grad.float().cpu() for k, p in m.named_parameters()})
+    for k in ("decoder.blocks.1.mlp.0.weight", "decoder.blocks.0.attn.query.weight", "decoder.ln_f.weight",
+              "decoder.input_parameter_projections.0.0.weight", "decoder.output_parameter_projections.2.0.weight"):
+        a, b = grads[1][k], grads[0][k]
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        assert cos > 0.99, (k, cos)
