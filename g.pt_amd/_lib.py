@@ -15,7 +15,7 @@ SRC_X, SRC_XPREV, SRC_SCALAR = 0, 1, 2
 NCOEF = 8
 C_SQRT_AC, C_SQRT_1MAC, C_POST1, C_POST2, C_LOGVAR, C_RECIP, C_RECIPM1, C_SPARE = range(8)
 
-vp, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
+vp, i32, i64, u64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double
 
 
 class Layer(C.Structure):
@@ -43,6 +43,11 @@ class Backward(C.Structure):
                [(n, vp) for n in ("g_pos_emb", "g_ln_in_w", "g_ln_in_b", "g_ln_f_w", "g_ln_f_b")] + \
                [("g_enc_w", vp * MAX_TOKENS), ("g_dec_w", vp * MAX_TOKENS)] + \
                [(n, vp) for n in ("g", "gt", "d_h", "d_qkv", "d_act", "tA", "tB", "d_tok")]
+
+
+class OptSegment(C.Structure):
+    _fields_ = [("start", i64), ("count", i64), ("packed_off", i64), ("k", i32), ("ld", i32), ("decay", i32),
+                ("reserved", i32)]
 
 
 class Workspace(C.Structure):
@@ -80,6 +85,10 @@ _PROTOS = {
     "gpt_perm_gather": ([C.POINTER(vp), C.POINTER(vp), i32, vp, i32, i32, vp], i32),
     "gpt_denoiser_forward": ([C.POINTER(Model), C.POINTER(Workspace), vp, vp, vp, vp, i32, vp, vp, i32, vp], i32),
     "gpt_denoiser_backward": ([C.POINTER(Model), C.POINTER(Workspace), C.POINTER(Backward), vp, vp, vp, i32, vp], i32),
+    "gpt_grad_sumsq": ([vp, i64, vp, vp, vp], i32),
+    "gpt_adamw_ema_step": ([vp, vp, vp, vp, vp, vp, i32, vp, i32, i64, vp, f32, f32, f64, f64, f64, f64, f64, i32, f64,
+                            i32, vp], i32),
+    "gpt_pack_segments": ([vp, vp, i32, vp, i32, i64, vp], i32),
     "gpt_sample_loop": ([C.POINTER(Model), C.POINTER(Workspace), vp, vp, vp, i32, vp, vp, C.POINTER(i64), i32, i32,
                          i32, i32, i32, f32, f32, vp, u64, vp, vp, vp, vp, i32, vp], i32),
 }

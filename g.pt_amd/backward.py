@@ -24,7 +24,7 @@ class GradArena:
         def take(name, numel):
             nonlocal off
             self.slices[name] = (off, numel)
-            off += (numel + 3) // 4 * 4       # keep every slice 16-byte aligned
+            off += (numel + 7) // 8 * 8       # every slice 32-byte aligned (16 bytes in a bf16 copy of the arena)
             return self.slices[name][0]
 
         self.layer_off = []
@@ -40,7 +40,7 @@ class GradArena:
             for nm in ("query", "key", "value"):
                 self.slices[p + f"attn.{nm}.bias"] = (off, d)
                 off += d
-            off = (off + 3) // 4 * 4
+            off = (off + 7) // 8 * 8
             lo["g_wproj"] = take(p + "attn.proj.weight", d * d)
             lo["g_bproj"] = take(p + "attn.proj.bias", d)
             lo["g_w1"] = take(p + "mlp.0.weight", 4 * d * d)
@@ -83,18 +83,19 @@ def _ensure_training_state(eng):
     lib = L.lib()
     if getattr(eng, "arena", None) is None:
         eng.arena = GradArena(m, eng.device)
-    keep = []
-    eng.wt = []
+    have = getattr(eng, "wt", None)
+    wt = []
     for l in range(dec.n_layer):
         ly = eng.cmodel.layers[l]
         d = dec.n_embd
         ts = {}
         for key, ptr, rows, cols in (("wqkv_t", ly.wqkv, 3 * d, d), ("wproj_t", ly.wproj, d, d), ("w1_t", ly.w1, 4 * d, d),
                                      ("w2_t", ly.w2, d, 4 * d)):
-            t = torch.empty(cols, rows, dtype=eng.tdtype, device=eng.device)
+            t = have[l][key] if have else torch.empty(cols, rows, dtype=eng.tdtype, device=eng.device)
             L.check(lib.gpt_transpose(eng.code, ptr, L.ptr(t), rows, cols, rows, L.stream()), "gpt_transpose")
             ts[key] = t
-        eng.wt.append(ts)
+        wt.append(ts)
+    eng.wt = wt
     eng._t_sig = eng.sig
 
 

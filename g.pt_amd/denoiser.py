@@ -202,7 +202,7 @@ class _Engine:
 
     # ---- weights
     def _signature(self):
-        return tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+        return (self.model._weights_epoch,) + tuple((p.data_ptr(), p._version) for p in self.model.parameters())
 
     def _cast(self, w):
         w = w.detach()
@@ -222,20 +222,31 @@ class _Engine:
             if p.device != self.device or p.dtype != torch.float32:
                 raise L.GptHipError("all G.pt parameters must be fp32 tensors on one GPU")
         keep = []
+        # parameters living in a flat arena (g.pt_amd/flat.py): the operands are the arena / its packed copy
+        flat = getattr(m, "_flat", None)
+        if flat is not None and not flat.bound(m):
+            flat = m._flat = None
+        if flat is not None:
+            flat.repack(self.code)
         layers = (L.Layer * dec.n_layer)()
         for l, blk in enumerate(dec.blocks):
             a = blk.attn
-            wqkv = self._cast(torch.cat([a.query.weight, a.key.weight, a.value.weight], 0))
-            bqkv = torch.cat([a.query.bias, a.key.bias, a.value.bias], 0).detach().contiguous()
-            wproj, w1, w2 = self._cast(a.proj.weight), self._cast(blk.mlp[0].weight), self._cast(blk.mlp[2].weight)
-            keep += [wqkv, bqkv, wproj, w1, w2]
             ly = layers[l]
             ly.ln1_w, ly.ln1_b = L.ptr(blk.ln1.weight), L.ptr(blk.ln1.bias)
             ly.ln2_w, ly.ln2_b = L.ptr(blk.ln2.weight), L.ptr(blk.ln2.bias)
-            ly.wqkv, ly.bqkv = L.ptr(wqkv), L.ptr(bqkv)
-            ly.wproj, ly.bproj = L.ptr(wproj), L.ptr(a.proj.bias)
-            ly.w1, ly.b1 = L.ptr(w1), L.ptr(blk.mlp[0].bias)
-            ly.w2, ly.b2 = L.ptr(w2), L.ptr(blk.mlp[2].bias)
+            if flat is not None:
+                pre = f"decoder.blocks.{l}."
+                ly.wqkv, ly.bqkv = flat.weight_ptr(self.code, pre + "attn.query.weight"), flat.param_ptr(pre + "attn.query.bias")
+                ly.wproj = flat.weight_ptr(self.code, pre + "attn.proj.weight")
+                ly.w1, ly.w2 = flat.weight_ptr(self.code, pre + "mlp.0.weight"), flat.weight_ptr(self.code, pre + "mlp.2.weight")
+            else:
+                wqkv = self._cast(torch.cat([a.query.weight, a.key.weight, a.value.weight], 0))
+                bqkv = torch.cat([a.query.bias, a.key.bias, a.value.bias], 0).detach().contiguous()
+                wproj, w1, w2 = self._cast(a.proj.weight), self._cast(blk.mlp[0].weight), self._cast(blk.mlp[2].weight)
+                keep += [wqkv, bqkv, wproj, w1, w2]
+                ly.wqkv, ly.bqkv = L.ptr(wqkv), L.ptr(bqkv)
+                ly.wproj, ly.w1, ly.w2 = L.ptr(wproj), L.ptr(w1), L.ptr(w2)
+            ly.bproj, ly.b1, ly.b2 = L.ptr(a.proj.bias), L.ptr(blk.mlp[0].bias), L.ptr(blk.mlp[2].bias)
         cm = L.Model()
         cm.dtype, cm.d, cm.n_head, cm.n_layer = self.code, dec.n_embd, dec.n_head, dec.n_layer
         cm.T, cm.D = dec.block_size, m.D
@@ -245,18 +256,26 @@ class _Engine:
         cm.ln_in_w, cm.ln_in_b = L.ptr(dec.ln_in.weight), L.ptr(dec.ln_in.bias)
         cm.ln_f_w, cm.ln_f_b = L.ptr(dec.ln_f.weight), L.ptr(dec.ln_f.bias)
         for i, (kind, off, k) in enumerate(m.token_sources):
-            w = dec.input_parameter_projections[i][0].weight.detach()
             kp = _round_up(k, 32)
-            wp = torch.zeros(w.shape[0], kp, dtype=torch.float32, device=self.device)
-            wp[:, :k] = w
-            wp = self._cast(wp)
-            keep.append(wp)
-            cm.enc_w[i], cm.enc_w_ld[i], cm.enc_k[i], cm.enc_src[i], cm.enc_off[i] = L.ptr(wp), kp, k, kind, off
+            if flat is not None:
+                wptr = flat.enc_ptr(self.code, i)
+            else:
+                w = dec.input_parameter_projections[i][0].weight.detach()
+                wp = torch.zeros(w.shape[0], kp, dtype=torch.float32, device=self.device)
+                wp[:, :k] = w
+                wp = self._cast(wp)
+                keep.append(wp)
+                wptr = L.ptr(wp)
+            cm.enc_w[i], cm.enc_w_ld[i], cm.enc_k[i], cm.enc_src[i], cm.enc_off[i] = wptr, kp, k, kind, off
         off = 0
         for j, n in enumerate(dec.output_splits):
-            w = self._cast(dec.output_parameter_projections[j][0].weight)
-            keep.append(w)
-            cm.dec_w[j], cm.dec_n[j], cm.dec_off[j] = L.ptr(w), n, off
+            if flat is not None:
+                wptr = flat.weight_ptr(self.code, f"decoder.output_parameter_projections.{j}.0.weight")
+            else:
+                w = self._cast(dec.output_parameter_projections[j][0].weight)
+                keep.append(w)
+                wptr = L.ptr(w)
+            cm.dec_w[j], cm.dec_n[j], cm.dec_off[j] = wptr, n, off
             off += n
         cm.layers = C.cast(layers, C.POINTER(L.Layer))
         keep.append(layers)
@@ -330,6 +349,8 @@ class Gpt(nn.Module):
         self.token_sources = self._token_sources(num_frequencies)
         self._compute_dtype = os.environ.get("GPT_AMD_DTYPE", "fp32")
         self._engines = {}
+        self._weights_epoch = 0          # bumped by writers that bypass torch's version counters (the fused step)
+        self._flat = None                # g.pt_amd/flat.py: FlatState once the parameters live in one arena
 
     # engines hold device pointers: never copy or pickle them with the module
     def __deepcopy__(self, memo):
@@ -338,12 +359,13 @@ class Gpt(nn.Module):
         memo[id(self)] = new
         from copy import deepcopy
         for k, v in self.__dict__.items():
-            new.__dict__[k] = {} if k == "_engines" else deepcopy(v, memo)
+            new.__dict__[k] = {} if k == "_engines" else None if k == "_flat" else deepcopy(v, memo)
         return new
 
     def __getstate__(self):
         st = dict(self.__dict__)
         st["_engines"] = {}
+        st["_flat"] = None
         return st
 
     @staticmethod

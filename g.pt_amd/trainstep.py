@@ -1,0 +1,246 @@
+"""One G.pt optimisation step, fused: the sequence of main.py:32-81 (run_diffusion_vlb + train_epoch body) without
+the autograd graph.
+
+    lr schedule -> t ~ U{0..999} -> x_t = q_sample(w_t1, t) -> denoiser forward (activations kept) -> per-row MSE
+    -> hand-written backward into ONE flat fp32 gradient arena -> bucketed RCCL all-reduce of the arena (overlapped
+    with the rest of the backward) -> global-norm clip -> AdamW (2 groups) -> EMA -> packed low-precision weights.
+
+`TrainStep` is what `bench.py --mode train` times; `diffusion.training_losses(model, ...)["loss"].backward()` with a
+stock torch optimizer (the reference's own loop) runs through g.pt_amd/backward.py and gives the same numbers
+(tests/test_hip_training.py pins both against the reference's fixtures).
+"""
+import ctypes as C
+import math
+import time
+from copy import deepcopy
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from . import dp
+from .backward import _ensure_training_state, backward_into, forward_keep
+from .ddpm import ModelMeanType
+from .flat import FlatState
+
+
+def lr_at(base_lr, num_ep, warmup_epochs, warmup_factor, cur_epoch, schedule="cos"):
+    """Gpt/utils.py:103-124: cosine (or fixed) schedule with a linear warm-up factor."""
+    lr = 0.5 * base_lr * (1.0 + math.cos(math.pi * cur_epoch / num_ep)) if schedule == "cos" else base_lr
+    if cur_epoch < warmup_epochs:
+        alpha = cur_epoch / warmup_epochs
+        lr *= warmup_factor * (1.0 - alpha) + alpha
+    return lr
+
+
+@torch.no_grad()
+def accumulate(ema, model, decay=0.9999):
+    """Gpt/utils.py:146-152 as two multi-tensor launches."""
+    pe = [p.data for _, p in sorted(ema.named_parameters())]
+    pm = [p.data for _, p in sorted(model.named_parameters())]
+    torch._foreach_mul_(pe, decay)
+    torch._foreach_add_(pe, pm, alpha=1 - decay)
+
+
+class TrainStep:
+    """One model replica's training state: flat arenas for parameters, gradients, AdamW moments and the EMA copy.
+
+    fused=True (default): clip + AdamW + EMA + operand re-packing run as gpt_grad_sumsq + ONE gpt_adamw_ema_step pass.
+    fused=False: the reference's own sequence on torch ops (clip_grad_norm_, torch.optim.AdamW from
+    configure_optimizers, accumulate) over the same gradient arena - the cross-check of the fused pass."""
+
+    def __init__(self, model, diffusion, lr=4e-4, wd=0.1, betas=(0.9, 0.999), eps=1e-8, grad_clip=0.75, ema_decay=0.9999,
+                 use_ema=True, bucket_layers=4, fused=True):
+        self.model, self.diffusion = model, diffusion
+        self.device = model.decoder.pos_emb.device
+        self.lr, self.wd, self.betas, self.eps = lr, wd, betas, eps
+        self.grad_clip, self.ema_decay, self.fused = grad_clip, ema_decay, fused
+        self.world = dp.get_world_size()
+        dp.broadcast_parameters(model)
+        self.ema = None
+        if use_ema:
+            self.ema = deepcopy(model)
+            for p in self.ema.parameters():
+                p.requires_grad = False
+        self.flat = FlatState(model, self.device)
+        self.flat_ema = FlatState(self.ema, self.device) if use_ema else None
+        self.eng = model.engine(self.device)
+        _ensure_training_state(self.eng)
+        self.code = self.eng.code
+        self.arena = self.flat.arena
+        self.grads = self.flat.like()
+        for p, g in zip(model.parameters(), self.flat.views(self.grads, model)):
+            p.grad = g
+        if fused:
+            self.exp_avg, self.exp_avg_sq = self.flat.like(), self.flat.like()
+            self.norm_scratch = torch.zeros(1024 + 4, dtype=torch.float32, device=self.device)
+            self.optimizer = None
+        else:
+            self.optimizer = model.configure_optimizers(lr=lr, wd=wd, betas=betas)
+        self.buckets = self._make_buckets(bucket_layers)
+        self.tmap = torch.tensor(diffusion._timestep_map(), device=self.device, dtype=torch.long)
+        self.iteration = 0
+
+    def _make_buckets(self, bucket_layers):
+        """Contiguous arena ranges in the order the backward finishes them: layer groups from the last to the first,
+        then the tensors outside the blocks (pos_emb, ln_in / ln_f, encoder and decoder Linears)."""
+        Lr = self.model.decoder.n_layer
+        starts = [self.arena.layer_off[l]["g_wqkv"] for l in range(Lr)] + [self.arena.glob["g_pos_emb"]]
+        out = []
+        hi = Lr
+        while hi > 0:
+            lo = max(0, hi - bucket_layers)
+            out.append((starts[lo], starts[hi]))
+            hi = lo
+        out.append((starts[Lr], self.arena.numel))
+        return out
+
+    def set_lr(self, lr):
+        self.lr = lr
+        if self.optimizer is not None:
+            for g in self.optimizer.param_groups:
+                g["lr"] = lr
+
+    @property
+    def grad_norm_sq(self):
+        return self.norm_scratch[1024:1025]
+
+    @torch.no_grad()
+    def loss_and_grads(self, w_t, w_t1, loss_t, loss_t1, t, weights=None, noise=None):
+        """run_diffusion_vlb (main.py:32-49) + backward of loss = mean(mse * weights) into the gradient arena
+        (which must be zero on entry).  Returns the per-sample mse."""
+        lib, dev = L.lib(), self.device
+        model, diff = self.model, self.diffusion
+        B, D = w_t1.shape
+        if noise is None:
+            noise = torch.empty_like(w_t1)
+            L.check(lib.gpt_randn(L.ptr(noise), noise.numel(), 0x5EED, self.iteration * self.world + dp.get_rank(),
+                                  L.stream()), "gpt_randn")
+        x_t = diff.q_sample(w_t1, t, noise=noise)
+        x, tm, lt, lp, xp = model._prepare(x_t, self.tmap[t], loss_t1, loss_t, w_t)
+        eng, ws, out = forward_keep(model, x, tm, lt, lp, xp)
+        target = w_t1 if diff.model_mean_type == ModelMeanType.START_X else noise
+        mse = torch.empty(B, dtype=torch.float32, device=dev)
+        L.check(lib.gpt_mse_rows(L.ptr(target), L.ptr(out), L.ptr(mse), B, D, L.stream()), "gpt_mse_rows")
+        g_rows = torch.full((B,), 1.0 / B, device=dev) if weights is None else (weights.float() / B).contiguous()
+        d_out = torch.empty_like(out)
+        L.check(lib.gpt_mse_rows_bwd(L.ptr(target), L.ptr(out), L.ptr(g_rows), L.ptr(d_out), B, D, L.stream()),
+                "gpt_mse_rows_bwd")
+        backward_into(eng, ws, x, xp, d_out, self.grads)
+        return mse
+
+    @torch.no_grad()
+    def exchange(self):
+        """DDP's gradient exchange (main.py:229-240): SUM all-reduce of the arena in a few large buckets; the 1/world
+        scale is folded into the optimizer pass."""
+        if self.world > 1:
+            handles = [dist.all_reduce(self.grads[lo:hi], async_op=True) for lo, hi in self.buckets]
+            for h in handles:
+                h.wait()
+
+    @torch.no_grad()
+    def update(self):
+        """clip -> AdamW -> EMA -> operand copies (main.py:66-74)."""
+        self.iteration += 1
+        model = self.model
+        if not self.fused:
+            if self.world > 1:
+                self.grads.mul_(1.0 / self.world)
+            if self.grad_clip > 0:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), self.grad_clip)
+            self.optimizer.step()
+            if self.ema is not None:
+                accumulate(self.ema, model, self.ema_decay)
+            self.grads.zero_()
+            return
+        lib, st = L.lib(), L.stream()
+        n = self.flat.numel
+        if self.grad_clip > 0:
+            L.check(lib.gpt_grad_sumsq(L.ptr(self.grads), n, L.ptr(self.norm_scratch), L.ptr(self.grad_norm_sq), st),
+                    "gpt_grad_sumsq")
+        seg, n_seg = self.flat.segments(self.code)
+        packed = self.flat.packed(self.code)
+        L.check(lib.gpt_adamw_ema_step(
+            L.ptr(self.flat.params), L.ptr(self.grads), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+            L.ptr(self.flat_ema.params) if self.flat_ema is not None else None, L.ptr(packed), self.code, L.ptr(seg), n_seg,
+            n, L.ptr(self.grad_norm_sq), float(self.grad_clip), 1.0 / self.world, self.lr, self.betas[0], self.betas[1],
+            self.eps, self.wd, self.iteration, self.ema_decay, 1, st), "gpt_adamw_ema_step")
+        # the step wrote the parameters, the EMA and this engine's operands behind torch's back
+        model._weights_epoch += 1
+        if self.ema is not None:
+            self.ema._weights_epoch += 1
+        self.eng.sig = self.eng._signature()
+        _ensure_training_state(self.eng)              # transposed dgrad operands of the new weights
+
+    def step(self, w_t, w_t1, loss_t, loss_t1, t, weights=None, noise=None):
+        """One optimisation step on one micro-batch; returns the per-sample mse (device tensor, no host sync)."""
+        mse = self.loss_and_grads(w_t, w_t1, loss_t, loss_t1, t, weights, noise)
+        self.exchange()
+        self.update()
+        return mse
+
+
+def synthetic_pairs(case, B, device, seed):
+    """checkpoint pairs of the MNIST shapes."""
+    from tests.cases import CASES
+    c = CASES[case]
+    D = sum(c["parameter_sizes"])
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    w_t = torch.randn(B, D, generator=g) * c["w_std"]
+    w_t1 = w_t + 0.1 * torch.randn(B, D, generator=g)
+    lo, hi = c["loss_lo"], c["loss_hi"]
+    loss_t = (lo + (hi - lo) * torch.rand(B, generator=g, dtype=torch.float64))
+    loss_t1 = (lo + (hi - lo) * torch.rand(B, generator=g, dtype=torch.float64))
+    return [v.to(device) for v in (w_t, w_t1, loss_t, loss_t1)]
+
+
+def bench_train(args, device, world, rank):
+    """bench.py --mode train: configs/train/mnist_loss.yaml hyper-parameters on synthetic checkpoint pairs."""
+    import gpt_amd
+    from bench import flops_per_forward, make_model, sync_all, PEAK
+    from tests.cases import CASES
+    case = args.case
+    B = args.batch or 128                      # int(1024 / 8): the per-GPU batch of the reference's 8-GPU run
+    torch.manual_seed(0)                       # same initial weights on every rank (then broadcast anyway)
+    model = make_model(case, args.dtype, device).train()
+    diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
+    sampler = gpt_amd.UniformSampler(diff)
+    np.random.seed(world + rank)               # Gpt/utils.py:73-75 with rng_seed = 1
+    ts = TrainStep(model, diff, lr=4e-4, wd=0.1, betas=(0.9, 0.999), grad_clip=0.75, ema_decay=0.9999)
+    batches = [synthetic_pairs(case, B, device, seed=1000 * rank + i) for i in range(4)]
+    iters_per_epoch = 1000
+
+    def run(n, first):
+        last = None
+        for i in range(first, first + n):
+            ts.set_lr(lr_at(4e-4, 25000, 5, 0.0, i / iters_per_epoch))
+            t, wts = sampler.sample(B, device)
+            last = ts.step(*batches[i % len(batches)], t, weights=wts)
+        return last
+
+    run(args.warmup, 0)
+    sync_all(world)
+    t0 = time.perf_counter()
+    mse = run(args.steps, args.warmup)
+    sync_all(world)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    loss = float(mse.mean().item())
+    assert math.isfinite(loss), "training diverged"
+    ms = elapsed * 1e3 / args.steps
+    flops = 3 * flops_per_forward(case) * B
+    return {
+        "metric": "train iters/sec (DDP)", "value": 1e3 / ms, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"configs/train/{case}_loss.yaml step on synthetic checkpoint pairs: q_sample + denoiser "
+                               f"forward/backward + grad all-reduce + clip 0.75 + AdamW(4e-4, wd 0.1) + EMA 0.9999; "
+                               f"B={B} pairs per GPU (global {B * world})",
+                   "batch_per_gpu": B, "global_batch": B * world},
+        "samples_per_s": B * world * 1e3 / ms, "model_tflops_per_gpu": flops / (ms * 1e-3) / 1e12,
+        "final_loss": loss,
+    }

@@ -258,6 +258,36 @@ int gpt_sample_loop(const gpt_model_t* m, const gpt_workspace_t* ws, float* x, c
                     const float* noise, uint64_t seed, int64_t* t_model, int64_t* t_index, float* model_out,
                     float* noise_buf, int B, void* stream);
 
+/* ---- optimizer step on one flat fp32 parameter arena (training-step harness, main.py:66-74) ----------------------
+ * A segment is one named parameter: `count` elements at element offset `start` of the arenas (starts are multiples
+ * of 4 elements; the gap up to the next start is zero padding).  decay: 1 = AdamW weight-decay group (Linear
+ * weights), 0 = no-decay group (biases, LayerNorm, pos_emb) - Gpt/models/transformer.py:163-213.
+ * packed_off >= 0: the updated values are also written, converted to the packed dtype, to element offset
+ * packed_off + (i / k) * ld + (i % k) of `packed` (k == ld: a plain cast copy; ld > k: rows zero-padded to ld,
+ * the encoder-weight operand layout of gpt_encode_tokens); packed_off < 0: no copy. */
+typedef struct {
+  int64_t start, count, packed_off;
+  int32_t k, ld, decay, reserved;
+} gpt_opt_segment_t;
+
+/* out[0] = sum(grads^2)   (the squared global norm of torch.nn.utils.clip_grad_norm_, main.py:70).
+ * scratch: fp32 [1024] device buffer.  n % 4 == 0. */
+int gpt_grad_sumsq(const float* grads, int64_t n, float* scratch, float* out, void* stream);
+
+/* One fused pass over the arenas (all fp32 [n], n % 4 == 0, 16-byte aligned; segments: DEVICE array sorted by start):
+ *   g' = grads * grad_scale * min(1, clip / (sqrt(*grad_norm_sq) * grad_scale + 1e-6))      (clip <= 0: no clipping)
+ *   torch.optim.AdamW single-tensor update of params / exp_avg / exp_avg_sq at step `step` (>= 1)
+ *   ema = ema * ema_decay + params * (1 - ema_decay)      (Gpt/utils.py:146-152; ema NULL: skipped)
+ *   packed copies per segment (packed NULL: skipped);  grads = 0 when zero_grad (optimizer.zero_grad, main.py:66). */
+int gpt_adamw_ema_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* ema, void* packed,
+                       int packed_dtype, const gpt_opt_segment_t* segments, int n_segments, int64_t n,
+                       const float* grad_norm_sq, float clip, float grad_scale, double lr, double beta1, double beta2,
+                       double eps, double weight_decay, int step, double ema_decay, int zero_grad, void* stream);
+
+/* The packed copies alone (after load_state_dict or any other write to the parameters that bypasses the step). */
+int gpt_pack_segments(const float* params, void* packed, int packed_dtype, const gpt_opt_segment_t* segments,
+                      int n_segments, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
