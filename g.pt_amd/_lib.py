@@ -80,11 +80,15 @@ _PROTOS = {
     "gpt_attention_bwd": ([i32, vp, vp, vp, i32, i32, i32, i32, vp], i32),
     "gpt_colsum": ([i32, vp, i64, vp, i32, i32, vp], i32),
     "gpt_small_gemm": ([i32, vp, i64, i64, i32, vp, i64, i64, vp, i64, i32, i32, i32, i32, vp], i32),
+    "gpt_small_gemm_batched": ([i32, i32, C.POINTER(vp), i64, i64, i32, C.POINTER(vp), i64, i64, C.POINTER(vp), C.POINTER(i32),
+                                C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i32, vp], i32),
     "gpt_perm_index_mlp": ([vp, vp, i32, i32, i32, i32, vp], i32),
     "gpt_perm_index_cnn": ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "gpt_perm_gather": ([C.POINTER(vp), C.POINTER(vp), i32, vp, i32, i32, vp], i32),
     "gpt_denoiser_forward": ([C.POINTER(Model), C.POINTER(Workspace), vp, vp, vp, vp, i32, vp, vp, i32, vp], i32),
     "gpt_denoiser_backward": ([C.POINTER(Model), C.POINTER(Workspace), C.POINTER(Backward), vp, vp, vp, i32, vp], i32),
+    "gpt_denoiser_backward_stages": ([C.POINTER(Model), C.POINTER(Workspace), C.POINTER(Backward), vp, vp, vp, i32, i32, i32,
+                                      vp], i32),
     "gpt_grad_sumsq": ([vp, i64, vp, vp, vp], i32),
     "gpt_adamw_ema_step": ([vp, vp, vp, vp, vp, vp, i32, vp, i32, i64, vp, f32, f32, f64, f64, f64, f64, f64, i32, f64,
                             i32, vp], i32),

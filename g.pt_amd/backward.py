@@ -153,13 +153,25 @@ def forward_keep(model, x, t, lt, lp, x_prev):
     return eng, ws, out
 
 
-def backward_into(eng, ws, x, x_prev, d_out, buf):
-    """Runs the backward of the last forward_keep on this engine, accumulating into the flat buffer `buf`."""
+def backward_into(eng, ws, x, x_prev, d_out, buf, schedule=None):
+    """Runs the backward of the last forward_keep on this engine, accumulating into the flat buffer `buf`.
+
+    schedule: optional [(stage_end, callback)] with increasing stage_end (stages as in gpt_denoiser_backward_stages):
+    each callback is called on the host right after the stages before its stage_end have been enqueued - the hook the
+    training step uses to put the gradient all-reduce of finished layers in flight behind them."""
     B = x.shape[0]
     scratch = _scratch(eng, B)
     bw, keep = _descriptor(eng, buf, scratch)
-    L.check(L.lib().gpt_denoiser_backward(C.byref(eng.cmodel), C.byref(ws), C.byref(bw), L.ptr(x), L.ptr(x_prev),
-                                          L.ptr(d_out), B, L.stream()), "gpt_denoiser_backward")
+    n_stages = eng.model.decoder.n_layer + 2
+    done = 0
+    for stage_end, callback in list(schedule or []) + [(n_stages, None)]:
+        if stage_end > done:
+            L.check(L.lib().gpt_denoiser_backward_stages(C.byref(eng.cmodel), C.byref(ws), C.byref(bw), L.ptr(x), L.ptr(x_prev),
+                                                         L.ptr(d_out), B, done, stage_end, L.stream()),
+                    "gpt_denoiser_backward_stages")
+            done = stage_end
+        if callback is not None:
+            callback()
     del keep
 
 

@@ -8,12 +8,31 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------ LayerNorm backward
-// One wave per row.  dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)); the row's contribution to
-// dgamma / dbeta is accumulated per workgroup in registers and flushed with one fp32 atomic per column per
-// workgroup (gamma/beta gradients are sums over all B*T rows).
+// One wave per row, the row held in registers (lane l owns columns 256 ch + 4 l .. + 3 of chunk ch < NCH).
+// dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)); the rows' contributions to dgamma / dbeta stay in
+// registers until the wave has done all its rows, then: one LDS add per wave, one fp32 global atomic per column per
+// workgroup (gamma / beta gradients are sums over all B*T rows).
 //   resid != NULL: gout = resid + dx (the residual-stream gradient passes the LayerNorm branch point)
 //   gout_t != NULL: also emits gout in the compute dtype (operand of the next dgrad / wgrad GEMMs)
-template <typename DyT, typename OutT>
+template <typename T>
+__device__ __forceinline__ f32x4 load_row4(const T* p);
+template <>
+__device__ __forceinline__ f32x4 load_row4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <>
+__device__ __forceinline__ f32x4 load_row4<bf16_t>(const bf16_t* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+               __uint_as_float(u.y & 0xffff0000u)};
+}
+__device__ __forceinline__ void store_row4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void store_row4(bf16_t* p, f32x4 v) {
+  uint2 u;
+  u.x = pack_bf16x2(v[0], v[1]);
+  u.y = pack_bf16x2(v[2], v[3]);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+
+template <typename DyT, typename OutT, int NCH>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ resid,
@@ -24,36 +43,73 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restric
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int c = threadIdx.x; c < 2 * d; c += 256) red[c] = 0.f;
   __syncthreads();
+  f32x4 gam[NCH], pg[NCH], pb[NCH];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int c = ch * 256 + lane * 4;
+    gam[ch] = c < d ? load_row4<float>(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    pg[ch] = pb[ch] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const int row_begin = blockIdx.x * rows_per_block;
   const int row_end = min(rows, row_begin + rows_per_block);
+  const float inv_d = 1.0f / (float)d;
   for (int row = row_begin + wave; row < row_end; row += 4) {
     const float mu = mean[row], rs = rstd[row];
-    const float* xr = x + (int64_t)row * d;
-    const DyT* dyr = dy + (int64_t)row * d;
+    const int64_t base = (int64_t)row * d;
+    f32x4 xh[NCH], dyv[NCH];
     float s1 = 0.f, s2 = 0.f;
-    for (int c = lane; c < d; c += 64) {
-      const float gdy = gamma[c] * elem<DyT>::load(dyr + c);
-      const float xh = (xr[c] - mu) * rs;
-      s1 += gdy;
-      s2 += gdy * xh;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c = ch * 256 + lane * 4;
+      if (c < d) {
+        xh[ch] = load_row4<float>(x + base + c);
+        dyv[ch] = load_row4<DyT>(dy + base + c);
+      } else {
+        xh[ch] = f32x4{mu, mu, mu, mu};
+        dyv[ch] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xh[ch][j] = (xh[ch][j] - mu) * rs;
+        const float gdy = gam[ch][j] * dyv[ch][j];
+        s1 += gdy;
+        s2 += gdy * xh[ch][j];
+      }
     }
-    s1 = wave_sum(s1) / (float)d;
-    s2 = wave_sum(s2) / (float)d;
-    for (int c = lane; c < d; c += 64) {
-      const float dyv = elem<DyT>::load(dyr + c);
-      const float xh = (xr[c] - mu) * rs;
-      float dx = rs * (gamma[c] * dyv - s1 - xh * s2);
-      if (resid) dx += resid[(int64_t)row * d + c];
-      gout[(int64_t)row * d + c] = dx;
-      if (gout_t) elem<OutT>::store(gout_t + (int64_t)row * d + c, dx);
-      atomicAdd(&red[c], dyv * xh);       // LDS atomics: 4 waves share the partial
-      atomicAdd(&red[d + c], dyv);
+    s1 = wave_sum(s1) * inv_d;
+    s2 = wave_sum(s2) * inv_d;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c = ch * 256 + lane * 4;
+      f32x4 dx;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dx[j] = rs * (gam[ch][j] * dyv[ch][j] - s1 - xh[ch][j] * s2);
+        pg[ch][j] += dyv[ch][j] * xh[ch][j];
+        pb[ch][j] += dyv[ch][j];
+      }
+      if (c < d) {
+        if (resid) dx += load_row4<float>(resid + base + c);
+        store_row4(gout + base + c, dx);
+        if (gout_t) store_row4(gout_t + base + c, dx);
+      }
+    }
+  }
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int c = ch * 256 + lane * 4;
+    if (c < d) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        atomicAdd(&red[c + j], pg[ch][j]);       // LDS: 4 waves share the workgroup partial
+        atomicAdd(&red[d + c + j], pb[ch][j]);
+      }
     }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < d; c += 256) {
-    atomicAdd(dgamma + c, red[c]);
-    atomicAdd(dbeta + c, red[d + c]);
+    unsafeAtomicAdd(dgamma + c, red[c]);          // hardware global_atomic_add_f32 (plain atomicAdd is a CAS loop)
+    unsafeAtomicAdd(dbeta + c, red[d + c]);
   }
 }
 
@@ -67,60 +123,86 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, in
   const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
   float s = 0.f;
   for (int r = r0; r < r1; ++r) s += elem<T>::load(X + (int64_t)r * ld + c);
-  atomicAdd(out + c, s);
+  unsafeAtomicAdd(out + c, s);
 }
 
 // ------------------------------------------------------------------------------------------ small strided GEMM
-// C[m, n] (+)= sum_k A(m, k) * B(k, n), fp32 FMA, arbitrary element strides: used for the ragged encoder /
-// decoder gradients (0.4 % of the FLOPs; K = batch or a token width).  64 x 64 tile, 16-deep LDS chunks.
+// C[m, n] (+)= sum_k A(m, k) * B(k, n), exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), arbitrary element strides: the
+// ragged encoder / decoder gradients (0.4 % of the FLOPs; K = batch or a token width).  64 x 64 tile per workgroup
+// (one 32 x 32 accumulator per wave), 32-deep chunks staged through LDS so either operand may be K- or M/N-major.
 template <typename TA, typename TB>
-__global__ __launch_bounds__(256) void small_gemm_kernel(const TA* __restrict__ A, int64_t a_sm, int64_t a_sk,
-                                                         const TB* __restrict__ B, int64_t b_sk, int64_t b_sn,
-                                                         float* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                         int accumulate) {
-  __shared__ float As[16][65], Bs[16][65];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+__device__ __forceinline__ void small_gemm_tile(const TA* __restrict__ A, int64_t a_sm, int64_t a_sk,
+                                                const TB* __restrict__ B, int64_t b_sk, int64_t b_sn,
+                                                float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                int accumulate) {
+  constexpr int KC = 32;
+  __shared__ float As[KC][65], Bs[KC][65];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  float acc[4][4] = {};
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    for (int i = threadIdx.x; i < 16 * 64; i += 256) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    for (int i = threadIdx.x; i < KC * 64; i += 256) {
       // lay the loads out along whichever index is contiguous in memory
       int kk, mm;
-      if (a_sk == 1) { kk = i & 15; mm = i >> 4; } else { mm = i & 63; kk = i >> 6; }
+      if (a_sk == 1) { kk = i & (KC - 1); mm = i / KC; } else { mm = i & 63; kk = i >> 6; }
       const int m = m0 + mm, k = k0 + kk;
       As[kk][mm] = (m < M && k < K) ? elem<TA>::load(A + m * a_sm + k * a_sk) : 0.f;
       int kb, nn;
-      if (b_sk == 1) { kb = i & 15; nn = i >> 4; } else { nn = i & 63; kb = i >> 6; }
+      if (b_sk == 1) { kb = i & (KC - 1); nn = i / KC; } else { nn = i & 63; kb = i >> 6; }
       const int n = n0 + nn, k2 = k0 + kb;
       Bs[kb][nn] = (n < N && k2 < K) ? elem<TB>::load(B + k2 * b_sk + n * b_sn) : 0.f;
     }
     __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      float a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx * 4 + j];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+    for (int kk = 0; kk < KC; kk += 2) {
+      const float a = As[kk + (lane >> 5)][wm + (lane & 31)];
+      const float b = Bs[kk + (lane >> 5)][wn + (lane & 31)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
     __syncthreads();
   }
+  const int n = n0 + wn + (lane & 31);
+  if (n < N) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + ty * 4 + i;
-    if (m >= M) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + tx * 4 + j;
-      if (n >= N) continue;
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (m >= M) continue;
       float* c = C + (int64_t)m * ldc + n;
-      *c = accumulate ? *c + acc[i][j] : acc[i][j];
+      *c = accumulate ? *c + acc[r] : acc[r];
     }
   }
+}
+
+template <typename TA, typename TB>
+__global__ __launch_bounds__(256) void small_gemm_kernel(const TA* __restrict__ A, int64_t a_sm, int64_t a_sk,
+                                                         const TB* __restrict__ B, int64_t b_sk, int64_t b_sn,
+                                                         float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                         int accumulate) {
+  small_gemm_tile<TA, TB>(A, a_sm, a_sk, B, b_sk, b_sn, C, ldc, M, N, K, accumulate);
+}
+
+// The same tile over a ragged batch of problems (blockIdx.z = problem): one launch for all tokens of the encoder /
+// decoder instead of one per token.
+constexpr int SG_MAX_PROBLEMS = 40;
+struct SmallGemmBatch {
+  const void* A[SG_MAX_PROBLEMS];
+  const void* B[SG_MAX_PROBLEMS];
+  float* C[SG_MAX_PROBLEMS];
+  int M[SG_MAX_PROBLEMS], N[SG_MAX_PROBLEMS], K[SG_MAX_PROBLEMS], ldc[SG_MAX_PROBLEMS];
+  int64_t a_sm, a_sk, b_sk, b_sn;
+  int accumulate;
+};
+
+template <typename TA, typename TB>
+__global__ __launch_bounds__(256) void small_gemm_batched_kernel(SmallGemmBatch g) {
+  const int z = blockIdx.z;
+  const int M = g.M[z], N = g.N[z];
+  if ((int)blockIdx.y * 64 >= M || (int)blockIdx.x * 64 >= N) return;      // uniform per workgroup
+  small_gemm_tile<TA, TB>((const TA*)g.A[z], g.a_sm, g.a_sk, (const TB*)g.B[z], g.b_sk, g.b_sn, g.C[z], g.ldc[z], M, N, g.K[z],
+                          g.accumulate);
 }
 
 // ------------------------------------------------------------------------------------------ attention backward
@@ -342,20 +424,30 @@ extern "C" int gpt_layernorm_bwd(const void* dy, int dy_dtype, const float* x, c
                                  const float* gamma, const float* resid, float* gout, void* gout_t, int gout_t_dtype,
                                  float* dgamma, float* dbeta, int rows, int d, void* stream) {
   GPT_REQUIRE(dy && x && mean && rstd && gamma && gout && dgamma && dbeta, "gpt_layernorm_bwd: null operand");
-  GPT_REQUIRE(rows > 0 && d > 0 && 2 * d * 4 <= 60000, "gpt_layernorm_bwd: bad sizes (d <= 7500)");
-  const int blocks = rows < 1024 ? (rows + 3) / 4 : 512;
+  GPT_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 3072, "gpt_layernorm_bwd: bad sizes (need d %% 4 == 0, d <= 3072)");
+  const int blocks = rows < 1024 ? (rows + 3) / 4 : 256;
   const int rpb = (rows + blocks - 1) / blocks;
   const dim3 grid((rows + rpb - 1) / rpb), block(256);
   const size_t lds = 2 * (size_t)d * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
-#define LNB(DY, OUT)                                                                                              \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<DY, OUT>), grid, block, lds, s, (const DY*)dy, x, mean, rstd, gamma, resid, \
-                     gout, (OUT*)gout_t, dgamma, dbeta, rows, d, rpb)
   const bool dyb = dy_dtype == GPT_BF16, ob = gout_t_dtype == GPT_BF16;
-  if (dyb && ob) LNB(bf16_t, bf16_t);
-  else if (dyb) LNB(bf16_t, float);
-  else if (ob) LNB(float, bf16_t);
-  else LNB(float, float);
+#define LNB(DY, OUT, NCH)                                                                                              \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<DY, OUT, NCH>), grid, block, lds, s, (const DY*)dy, x, mean, rstd, gamma, resid, \
+                     gout, (OUT*)gout_t, dgamma, dbeta, rows, d, rpb)
+#define LNB_T(NCH)                         \
+  do {                                     \
+    if (dyb && ob) LNB(bf16_t, bf16_t, NCH); \
+    else if (dyb) LNB(bf16_t, float, NCH); \
+    else if (ob) LNB(float, bf16_t, NCH);  \
+    else LNB(float, float, NCH);           \
+  } while (0)
+  if (d <= 256) LNB_T(1);
+  else if (d <= 512) LNB_T(2);
+  else if (d <= 1024) LNB_T(4);
+  else if (d <= 1536) LNB_T(6);
+  else if (d <= 2048) LNB_T(8);
+  else LNB_T(12);
+#undef LNB_T
 #undef LNB
   return gpt_launch_status("gpt_layernorm_bwd");
 }
@@ -418,4 +510,33 @@ extern "C" int gpt_attention_bwd(int dtype, const void* qkv, const void* dy, voi
   }
 #undef AB
   return gpt_launch_status("gpt_attention_bwd");
+}
+
+extern "C" int gpt_small_gemm_batched(int n_problems, int a_dtype, const void* const* host_A, int64_t a_sm, int64_t a_sk,
+                                      int b_dtype, const void* const* host_B, int64_t b_sk, int64_t b_sn, float* const* host_C,
+                                      const int* host_ldc, const int* host_M, const int* host_N, const int* host_K,
+                                      int accumulate, void* stream) {
+  GPT_REQUIRE(n_problems > 0 && n_problems <= SG_MAX_PROBLEMS, "gpt_small_gemm_batched: 1..%d problems", SG_MAX_PROBLEMS);
+  GPT_REQUIRE(host_A && host_B && host_C && host_ldc && host_M && host_N && host_K, "gpt_small_gemm_batched: null array");
+  SmallGemmBatch g;
+  int max_m = 0, max_n = 0;
+  for (int i = 0; i < n_problems; ++i) {
+    GPT_REQUIRE(host_A[i] && host_B[i] && host_C[i] && host_M[i] > 0 && host_N[i] > 0 && host_K[i] > 0 && host_ldc[i] >= host_N[i],
+                "gpt_small_gemm_batched: problem %d: bad arguments", i);
+    g.A[i] = host_A[i]; g.B[i] = host_B[i]; g.C[i] = host_C[i];
+    g.M[i] = host_M[i]; g.N[i] = host_N[i]; g.K[i] = host_K[i]; g.ldc[i] = host_ldc[i];
+    max_m = host_M[i] > max_m ? host_M[i] : max_m;
+    max_n = host_N[i] > max_n ? host_N[i] : max_n;
+  }
+  g.a_sm = a_sm; g.a_sk = a_sk; g.b_sk = b_sk; g.b_sn = b_sn; g.accumulate = accumulate;
+  const dim3 grid((max_n + 63) / 64, (max_m + 63) / 64, n_problems), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define SGB(TA, TB) hipLaunchKernelGGL((small_gemm_batched_kernel<TA, TB>), grid, block, 0, s, g)
+  const bool ab = a_dtype == GPT_BF16, bb = b_dtype == GPT_BF16;
+  if (ab && bb) SGB(bf16_t, bf16_t);
+  else if (ab) SGB(bf16_t, float);
+  else if (bb) SGB(float, bf16_t);
+  else SGB(float, float);
+#undef SGB
+  return gpt_launch_status("gpt_small_gemm_batched");
 }

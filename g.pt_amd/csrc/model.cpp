@@ -115,7 +115,16 @@ extern "C" int gpt_sample_loop(const gpt_model_t* m, const gpt_workspace_t* ws, 
 
 extern "C" int gpt_denoiser_backward(const gpt_model_t* m, const gpt_workspace_t* ws, const gpt_backward_t* bw,
                                      const float* x, const float* x_prev, const float* d_out, int B, void* stream) {
+  GPT_REQUIRE(m, "gpt_denoiser_backward: null model");
+  return gpt_denoiser_backward_stages(m, ws, bw, x, x_prev, d_out, B, 0, m->n_layer + 2, stream);
+}
+
+extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_workspace_t* ws, const gpt_backward_t* bw,
+                                            const float* x, const float* x_prev, const float* d_out, int B, int stage_begin,
+                                            int stage_end, void* stream) {
   CHECK(validate(m, ws, B, "gpt_denoiser_backward"));
+  GPT_REQUIRE(0 <= stage_begin && stage_begin < stage_end && stage_end <= m->n_layer + 2,
+              "gpt_denoiser_backward_stages: bad stage range [%d, %d) of %d", stage_begin, stage_end, m->n_layer + 2);
   GPT_REQUIRE(bw && bw->layers && x && x_prev && d_out, "gpt_denoiser_backward: null operand");
   GPT_REQUIRE(ws->layer_stride == 1, "gpt_denoiser_backward: needs the workspace of a training forward");
   const int d = m->d, T = m->T, M = B * T, L = m->n_layer, dt = m->dtype;
@@ -134,18 +143,33 @@ extern "C" int gpt_denoiser_backward(const gpt_model_t* m, const gpt_workspace_t
     return gpt_gemm_nt(dt, bw->tA, Mp, bw->tB, Mp, nullptr, gW, k_in, nullptr, 0, n_out, k_in, (int)Mp, GPT_EPI_ACCUM_F32, stream);
   };
 
-  // decoder: d_tok[b, j, :] = d_out[b, off_j..] . W_j   (zero for the tokens that are not decoded);  dW_j += d_out_j^T . hf_j
+  // stage 0 - decoder: d_tok[b, j, :] = d_out[b, off_j..] . W_j (zero for the tokens that are not decoded);  dW_j += d_out_j^T . hf_j
+  if (stage_begin == 0) {
   if (hipMemsetAsync(bw->d_tok, 0, (size_t)M * d * sizeof(float), hs) != hipSuccess) { gpt_set_error("memset failed"); return -1; }
-  for (int j = 0; j < m->n_out_tok; ++j) {
-    const float* dj = d_out + m->dec_off[j];
-    CHECK(gpt_small_gemm(GPT_F32, dj, m->D, 1, dt, m->dec_w[j], d, 1, bw->d_tok + (size_t)j * d, (int64_t)T * d, B, d, m->dec_n[j], 0, stream));
-    CHECK(gpt_small_gemm(GPT_F32, dj, 1, m->D, dt, (const char*)ws->hf + (size_t)j * d * es, (int64_t)T * d, 1, bw->g_dec_w[j], d,
-                         m->dec_n[j], d, B, 1, stream));
+  {
+    const void *pa[GPT_MAX_TOKENS], *pw[GPT_MAX_TOKENS], *ph[GPT_MAX_TOKENS];
+    float *pt[GPT_MAX_TOKENS], *pg[GPT_MAX_TOKENS];
+    int vB[GPT_MAX_TOKENS], vd[GPT_MAX_TOKENS], vn[GPT_MAX_TOKENS], vTd[GPT_MAX_TOKENS];
+    for (int j = 0; j < m->n_out_tok; ++j) {
+      pa[j] = d_out + m->dec_off[j];
+      pw[j] = m->dec_w[j];
+      ph[j] = (const char*)ws->hf + (size_t)j * d * es;
+      pt[j] = bw->d_tok + (size_t)j * d;
+      pg[j] = bw->g_dec_w[j];
+      vB[j] = B; vd[j] = d; vn[j] = m->dec_n[j]; vTd[j] = T * d;
+    }
+    // d_tok[b, j, :] = d_out[b, off_j ..] . W_j            (M = B, N = d, K = n_j)
+    CHECK(gpt_small_gemm_batched(m->n_out_tok, GPT_F32, pa, m->D, 1, dt, pw, d, 1, pt, vTd, vB, vd, vn, 0, stream));
+    // dW_j[n, :] += sum_b d_out[b, off_j + n] hf[b, j, :]   (M = n_j, N = d, K = B)
+    CHECK(gpt_small_gemm_batched(m->n_out_tok, GPT_F32, pa, 1, m->D, dt, ph, (int64_t)T * d, 1, pg, vd, vn, vd, vB, 1, stream));
   }
   CHECK(gpt_layernorm_bwd(bw->d_tok, GPT_F32, xbuf(2 * L), stat(2 * L + 1, 0), stat(2 * L + 1, 1), m->ln_f_w, nullptr, bw->g, bw->gt, dt,
                           bw->g_ln_f_w, bw->g_ln_f_b, M, d, stream));
+  }
 
+  // stages 1 .. L - the blocks, last to first (stage s = layer L - s)
   for (int l = L - 1; l >= 0; --l) {
+    if (L - l < stage_begin || L - l >= stage_end) continue;
     const gpt_layer_t& ly = m->layers[l];
     const gpt_layer_grad_t& gl = bw->layers[l];
     const void* h1 = lay(ws->h1, l, d);
@@ -176,20 +200,31 @@ extern "C" int gpt_denoiser_backward(const gpt_model_t* m, const gpt_workspace_t
     CHECK(gpt_layernorm_bwd(bw->d_h, dt, xbuf(2 * l), stat(1 + 2 * l, 0), stat(1 + 2 * l, 1), ly.ln1_w, bw->g, bw->g, bw->gt, dt,
                             gl.g_ln1_w, gl.g_ln1_b, M, d, stream));
   }
-  // position embedding: sum over the batch of the gradient of x0 = ln_in(enc) + pos_emb
+  if (stage_end < L + 2) return 0;
+  // stage L + 1 - position embedding: sum over the batch of the gradient of x0 = ln_in(enc) + pos_emb
   CHECK(gpt_colsum(GPT_F32, bw->g, (int64_t)T * d, bw->g_pos_emb, B, T * d, stream));
   CHECK(gpt_layernorm_bwd(bw->g, GPT_F32, ws->enc, stat(0, 0), stat(0, 1), m->ln_in_w, nullptr, bw->d_tok, nullptr, GPT_F32,
                           bw->g_ln_in_w, bw->g_ln_in_b, M, d, stream));
-  for (int i = 0; i < T; ++i) {
-    const float* src;
-    int64_t src_ld;
-    switch (m->enc_src[i]) {
-      case GPT_SRC_X: src = x + m->enc_off[i]; src_ld = m->D; break;
-      case GPT_SRC_XPREV: src = x_prev + m->enc_off[i]; src_ld = m->D; break;
-      default: src = ws->scal + m->enc_off[i]; src_ld = (int64_t)m->n_scalar * W; break;
+  {
+    // dW_i[:, k] += sum_b d_tok[b, i, :] src_i[b, k]        (M = d, N = k_i, K = B); sources grouped by their row stride
+    const int64_t ld_scal = (int64_t)m->n_scalar * W;
+    for (int pass = 0; pass < 2; ++pass) {
+      const void *pa[GPT_MAX_TOKENS], *pb[GPT_MAX_TOKENS];
+      float* pc[GPT_MAX_TOKENS];
+      int vM[GPT_MAX_TOKENS], vN[GPT_MAX_TOKENS], vK[GPT_MAX_TOKENS], vld[GPT_MAX_TOKENS];
+      int n = 0;
+      for (int i = 0; i < T; ++i) {
+        const bool scalar = m->enc_src[i] == GPT_SRC_SCALAR;
+        if (scalar != (pass == 1)) continue;
+        pa[n] = bw->d_tok + (size_t)i * d;
+        pb[n] = scalar ? ws->scal + m->enc_off[i] : (m->enc_src[i] == GPT_SRC_X ? x : x_prev) + m->enc_off[i];
+        pc[n] = bw->g_enc_w[i];
+        vM[n] = d; vN[n] = m->enc_k[i]; vK[n] = B; vld[n] = m->enc_k[i];
+        ++n;
+      }
+      if (n) CHECK(gpt_small_gemm_batched(n, GPT_F32, pa, 1, (int64_t)T * d, GPT_F32, pb, pass ? ld_scal : (int64_t)m->D, 1, pc, vld,
+                                          vM, vN, vK, 1, stream));
     }
-    CHECK(gpt_small_gemm(GPT_F32, bw->d_tok + (size_t)i * d, 1, (int64_t)T * d, GPT_F32, src, src_ld, 1, bw->g_enc_w[i], m->enc_k[i],
-                         d, m->enc_k[i], B, 1, stream));
   }
   return 0;
 }

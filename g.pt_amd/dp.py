@@ -89,11 +89,20 @@ def gather_rows(local, n_rows):
 
 
 def broadcast_parameters(module, src=0):
-    """Initial parameter broadcast from rank 0 (what DDP does at construction, main.py:231-236)."""
+    """Initial parameter broadcast from rank 0 (what DDP does at construction, main.py:231-236), coalesced into one
+    message per dtype instead of one collective per tensor."""
     if get_world_size() == 1:
         return
+    by_dtype = {}
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src)
+        by_dtype.setdefault(t.dtype, []).append(t.data)
+    for tensors in by_dtype.values():
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        dist.broadcast(flat, src=src)
+        off = 0
+        for t in tensors:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
 
 
 class GradBuckets:
@@ -145,3 +154,26 @@ class GradBuckets:
             h.wait()
             self.buckets[i].mul_(1.0 / w)
         self.pending = []
+
+
+def all_reduce_ranges(flat, ranges, async_op=True):
+    """SUM all-reduce of contiguous [lo, hi) element ranges of one flat buffer, one collective per range, launched in
+    the given order (the order the backward finishes them) and left in flight; returns the work handles.
+    The 1/world scale is NOT applied (the fused optimizer pass folds it in).
+    A process group without a device transport (gloo: the CPU rehearsal of the multi-GPU path) gets device buffers
+    staged through the host, synchronously."""
+    if get_world_size() == 1:
+        return []
+    if flat.is_cuda and dist.get_backend() != "nccl":
+        for lo, hi in ranges:
+            host = flat[lo:hi].cpu()
+            dist.all_reduce(host)
+            flat[lo:hi].copy_(host)
+        return []
+    return [dist.all_reduce(flat[lo:hi], async_op=async_op) for lo, hi in ranges]
+
+
+def wait_all(handles):
+    for h in handles:
+        if h is not None:
+            h.wait()

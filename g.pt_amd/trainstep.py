@@ -51,19 +51,21 @@ class TrainStep:
     configure_optimizers, accumulate) over the same gradient arena - the cross-check of the fused pass."""
 
     def __init__(self, model, diffusion, lr=4e-4, wd=0.1, betas=(0.9, 0.999), eps=1e-8, grad_clip=0.75, ema_decay=0.9999,
-                 use_ema=True, bucket_layers=4, fused=True):
+                 use_ema=True, bucket_layers=4, fused=True, overlap=True):
         self.model, self.diffusion = model, diffusion
         self.device = model.decoder.pos_emb.device
         self.lr, self.wd, self.betas, self.eps = lr, wd, betas, eps
-        self.grad_clip, self.ema_decay, self.fused = grad_clip, ema_decay, fused
+        self.grad_clip, self.ema_decay, self.fused, self.overlap = grad_clip, ema_decay, fused, overlap
+        self._handles = []
         self.world = dp.get_world_size()
-        dp.broadcast_parameters(model)
+        self.flat = FlatState(model, self.device)
+        if self.world > 1:                              # rank 0's weights everywhere (DDP construction, main.py:231-236)
+            dist.broadcast(self.flat.params, src=0)
         self.ema = None
         if use_ema:
             self.ema = deepcopy(model)
             for p in self.ema.parameters():
                 p.requires_grad = False
-        self.flat = FlatState(model, self.device)
         self.flat_ema = FlatState(self.ema, self.device) if use_ema else None
         self.eng = model.engine(self.device)
         _ensure_training_state(self.eng)
@@ -87,13 +89,13 @@ class TrainStep:
         then the tensors outside the blocks (pos_emb, ln_in / ln_f, encoder and decoder Linears)."""
         Lr = self.model.decoder.n_layer
         starts = [self.arena.layer_off[l]["g_wqkv"] for l in range(Lr)] + [self.arena.glob["g_pos_emb"]]
-        out = []
+        out = []                           # (lo, hi, stage_end): complete once the backward stages < stage_end ran
         hi = Lr
         while hi > 0:
             lo = max(0, hi - bucket_layers)
-            out.append((starts[lo], starts[hi]))
+            out.append((starts[lo], starts[hi], Lr - lo + 1))
             hi = lo
-        out.append((starts[Lr], self.arena.numel))
+        out.append((starts[Lr], self.arena.numel, Lr + 2))
         return out
 
     def set_lr(self, lr):
@@ -127,17 +129,24 @@ class TrainStep:
         d_out = torch.empty_like(out)
         L.check(lib.gpt_mse_rows_bwd(L.ptr(target), L.ptr(out), L.ptr(g_rows), L.ptr(d_out), B, D, L.stream()),
                 "gpt_mse_rows_bwd")
-        backward_into(eng, ws, x, xp, d_out, self.grads)
+        # DDP's gradient exchange (main.py:229-240): the SUM all-reduce of a bucket goes in flight on RCCL's stream as
+        # soon as the backward stages that fill it are enqueued, and overlaps with the remaining stages
+        self._handles = []
+        schedule = None
+        if self.world > 1 and self.overlap:
+            schedule = [(stage_end, (lambda lo=lo, hi=hi: self._handles.extend(dp.all_reduce_ranges(self.grads, [(lo, hi)]))))
+                        for lo, hi, stage_end in self.buckets]
+        backward_into(eng, ws, x, xp, d_out, self.grads, schedule)
         return mse
 
     @torch.no_grad()
     def exchange(self):
-        """DDP's gradient exchange (main.py:229-240): SUM all-reduce of the arena in a few large buckets; the 1/world
-        scale is folded into the optimizer pass."""
-        if self.world > 1:
-            handles = [dist.all_reduce(self.grads[lo:hi], async_op=True) for lo, hi in self.buckets]
-            for h in handles:
-                h.wait()
+        """Completes the gradient exchange (launches it here when not overlapped); the 1/world scale is folded into the
+        optimizer pass."""
+        if self.world > 1 and not self.overlap:
+            self._handles = dp.all_reduce_ranges(self.grads, [(lo, hi) for lo, hi, _ in self.buckets])
+        dp.wait_all(self._handles)
+        self._handles = []
 
     @torch.no_grad()
     def update(self):

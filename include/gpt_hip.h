@@ -151,6 +151,14 @@ int gpt_small_gemm(int a_dtype, const void* A, int64_t a_sm, int64_t a_sk, int b
                    int64_t b_sk, int64_t b_sn, float* C, int64_t ldc, int M, int N, int K, int accumulate,
                    void* stream);
 
+/* gpt_small_gemm over a ragged batch of problems in ONE launch (<= 40; all tokens of the encoder or the decoder).
+ * The pointer / size arrays are host arrays (copied into the kernel arguments); element strides and dtypes are
+ * shared, every problem has its own M, N, K and ldc. */
+int gpt_small_gemm_batched(int n_problems, int a_dtype, const void* const* host_A, int64_t a_sm, int64_t a_sk,
+                           int b_dtype, const void* const* host_B, int64_t b_sk, int64_t b_sn, float* const* host_C,
+                           const int* host_ldc, const int* host_M, const int* host_N, const int* host_K,
+                           int accumulate, void* stream);
+
 /* Permutation augmentation (Gpt/data/augment.py:25-75 with data_gen/train_mnist.py:28-50 and
  * data_gen/train_cifar10.py:27-47).  perms: int32 device array [n_samples, perm_len] holding, per sample,
  * the hidden-unit permutations back to back (MLP: p[H]; CNN: p1[C1] then p2[C2]).
@@ -240,6 +248,14 @@ typedef struct {
  * x / x_prev / t inputs are not differentiated (training_losses needs parameter gradients only). */
 int gpt_denoiser_backward(const gpt_model_t* m, const gpt_workspace_t* ws, const gpt_backward_t* bw, const float* x,
                           const float* x_prev, const float* d_out, int B, void* stream);
+
+/* The same backward in stages, so that the host can start the gradient all-reduce of finished layers while the
+ * rest still runs (what DistributedDataParallel's bucketed reducer does for main.py:229-240).  Stage 0 = decoder
+ * Linears + ln_f; stage s in 1..n_layer = block n_layer - s; stage n_layer + 1 = pos_emb, ln_in, encoder Linears.
+ * Runs stages [stage_begin, stage_end) - consecutive calls must cover 0 .. n_layer + 2 in order on one stream. */
+int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_workspace_t* ws, const gpt_backward_t* bw,
+                                 const float* x, const float* x_prev, const float* d_out, int B, int stage_begin,
+                                 int stage_end, void* stream);
 
 /* out[B, D] = Gpt.forward(x, t, loss_target, loss_prev, x_prev)   (transformer.py:440-464) */
 int gpt_denoiser_forward(const gpt_model_t* m, const gpt_workspace_t* ws, const float* x, const int64_t* t,

@@ -223,3 +223,69 @@ def test_fused_step_matches_torch_optimizer_over_steps():
                 continue      # its true gradient is zero (softmax is shift invariant): Adam normalises pure rounding noise
             # bf16 operand rounding can flip a few low bits of the gradients between the two runs' packed weights
             assert float((a[k] - b[k]).abs().max()) < 2e-4 * max(1.0, float(b[k].abs().max())), k
+
+
+# ---------------------------------------------------------------------------------------------- data parallel
+def _ddp_rank(rank, world, port, out_path):
+    """One rank of a 2-process data-parallel step; both ranks use GPU 0 (the box has one), so the exchange runs on gloo."""
+    import faulthandler
+    import os
+    import torch.distributed as dist
+    faulthandler.dump_traceback_later(90, exit=True)            # a stuck collective must end the rank, not the box
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gpt_amd.trainstep import TrainStep
+        m, plan, sd = build("mnist_small", "fp32", seed=3 + rank)       # different weights: rank 0's must win the broadcast
+        m.train()
+        diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
+        ts = TrainStep(m, diff, lr=1e-3, wd=0.1, grad_clip=0.75, bucket_layers=1)
+        for i in range(2):
+            batch = _ddp_batch(i)
+            sl = slice(rank * 4, rank * 4 + 4)
+            ts.step(*(v[sl] for v in batch))
+        if rank == 0:
+            torch.save({k: p.detach().cpu() for k, p in m.named_parameters()}, out_path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _ddp_batch(i):
+    _, _, lt, lp, xp = (v.to(DEV) for v in make_inputs("mnist_small", B=8, seed=80 + i))
+    gen = torch.Generator().manual_seed(90 + i)
+    x1 = xp + 0.1 * torch.randn(xp.shape, generator=gen).to(DEV)
+    t = torch.randint(0, 1000, (8,), generator=gen).to(DEV)
+    noise = torch.randn(xp.shape, generator=gen).to(DEV)
+    return xp, x1, lp, lt, t, torch.ones(8, device=DEV), noise
+
+
+def test_two_rank_step_equals_full_batch(tmp_path):
+    """2 ranks x 4 rows with the staged, overlapped gradient exchange == 1 process x 8 rows (two steps, fp32)."""
+    import socket
+    import torch.multiprocessing as mp
+    from gpt_amd.trainstep import TrainStep
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out_path = str(tmp_path / "rank0.pt")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_ddp_rank, args=(r, 2, port, out_path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        if p.exitcode is None:
+            p.kill()
+        assert p.exitcode == 0
+    got = torch.load(out_path, weights_only=True)
+    m, plan, sd = build("mnist_small", "fp32", seed=3)
+    m.train()
+    diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
+    ts = TrainStep(m, diff, lr=1e-3, wd=0.1, grad_clip=0.75)
+    for i in range(2):
+        ts.step(*_ddp_batch(i))
+    for k, p in m.named_parameters():
+        if k.endswith("attn.key.bias"):
+            continue
+        assert float((p.detach().cpu() - got[k]).abs().max()) < 5e-5 * max(1.0, float(got[k].abs().max())), k
