@@ -104,3 +104,32 @@ def test_uniform_sampler():
     np.random.seed(5)
     assert t.tolist() == np.random.choice(1000, size=(16,), p=np.ones(1000) / 1000).tolist()
     assert t.dtype == torch.int64 and w.dtype == torch.float32 and torch.all(w == 1)
+
+
+def test_reference_import_paths_resolve_to_the_hip_host():
+    """The module paths the reference's callers import (main.py:18-26, playground.py:7-14) exist in the shim."""
+    import importlib
+    import os
+    import sys
+    compat = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "g.pt_amd", "compat")
+    saved = {k: v for k, v in sys.modules.items() if k == "Gpt" or k.startswith("Gpt.")}
+    for k in saved:
+        del sys.modules[k]
+    sys.path.insert(0, compat)
+    try:
+        import gpt_amd
+        tr = importlib.import_module("Gpt.models.transformer")
+        df = importlib.import_module("Gpt.diffusion")
+        tsamp = importlib.import_module("Gpt.diffusion.timestep_sampler")
+        dd = importlib.import_module("Gpt.distributed")
+        assert tr.Gpt is gpt_amd.Gpt and df.create_diffusion is gpt_amd.create_diffusion
+        assert tsamp.UniformSampler is gpt_amd.UniformSampler
+        for name in ("scaled_all_reduce", "get_rank", "get_world_size", "is_main_proc", "synchronize", "all_gather", "rank0_to_all"):
+            assert callable(getattr(dd, name))
+        gd = importlib.import_module("Gpt.diffusion.gaussian_diffusion")
+        assert hasattr(gd, "GaussianDiffusion") and hasattr(gd, "ModelMeanType")
+    finally:
+        sys.path.remove(compat)
+        for k in [k for k in sys.modules if k == "Gpt" or k.startswith("Gpt.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
