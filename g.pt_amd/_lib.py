@@ -6,7 +6,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgpt_hip.so")
+LIB_PATH = os.environ.get("GPT_HIP_LIB") or os.path.join(_HERE, "lib", "libgpt_hip.so")   # override: kernel experiments
 
 F32, BF16 = 0, 1
 EPI_STORE, EPI_GELU, EPI_RESADD, EPI_STORE_F32, EPI_GELU_AUX, EPI_DGELU, EPI_ACCUM_F32 = range(7)

@@ -30,6 +30,7 @@
 namespace gemmk {
 GemmProf g_prof;
 int gemm256_bf16(const GemmArgs<bf16_t>& g, int epi, hipStream_t s);  // gemm256.hip
+bool gemm256_stream_k(const GemmArgs<bf16_t>& g, int epi);            // gemm256.hip: would run as stream-K
 int gemm256_f32(const GemmArgs<float>& g, int epi, hipStream_t s);
 }
 
@@ -188,12 +189,61 @@ int tile_mode() {
 }
 
 template <typename T>
+int dispatch_ring(const GemmArgs<T>& g, int epi, hipStream_t s);
+
+// Rows [0, m_main) of the problem for the 256 x 256 kernel, the rest for the finer-grained ring kernels.
+// The 256 x 256 kernel runs one workgroup per CU, so a launch costs ceil(tiles / 256) full rounds however empty the
+// last one is (B = 320: 594 tiles -> 3 rounds at 77 %).  When the last round would be poorly filled, the row-tiles
+// that do not fill whole rounds are handed to the 128 x 128 kernel (2 workgroups per CU, a quarter of the work each).
+template <typename T>
+int split_rows(const GemmArgs<T>& g) {
+  static const int n_cu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  static const bool enabled = [] {
+    const char* e = getenv("GPT_GEMM_SPLIT");  // 0 disables (experiments)
+    return !e || atoi(e) != 0;
+  }();
+  const int tn = (g.N + 255) / 256, tm = (g.M + 255) / 256, tiles = tm * tn;
+  const int rounds = tiles / n_cu, rem = tiles % n_cu;
+  if (!enabled || rounds == 0 || rem == 0 || rem * 10 > n_cu * 6) return g.M;
+  const int main_tiles_m = rounds * n_cu / tn;
+  const int m_main = main_tiles_m * 256;
+  if (m_main <= 0 || m_main >= g.M) return g.M;
+  const int tail128 = ((g.M - m_main + 127) / 128) * ((g.N + 127) / 128);
+  const double cost_split = rounds + 0.5 * ((tail128 + 2 * n_cu - 1) / (2 * n_cu)) + 0.08;
+  return cost_split < rounds + 1 ? m_main : g.M;
+}
+
+template <typename T>
 int dispatch(const GemmArgs<T>& g, int epi, hipStream_t s) {
   const int tiles256 = ((g.M + 255) / 256) * ((g.N + 255) / 256);
-  if (tile_mode() == 3 || (tile_mode() == 0 && tiles256 >= 128)) {
-    if constexpr (sizeof(T) == 2) return gemm256_bf16(g, epi, s);
-    else return gemm256_f32(g, epi, s);
+  bool sk = false;
+  if constexpr (sizeof(T) == 2) sk = tile_mode() == 0 && tiles256 >= 16 && gemm256_stream_k(g, epi);
+  if (tile_mode() == 3 || (tile_mode() == 0 && tiles256 >= 128) || sk) {
+    const int m_main = tile_mode() == 0 && !sk ? split_rows(g) : g.M;
+    GemmArgs<T> head = g;
+    head.M = m_main;
+    int rc;
+    if constexpr (sizeof(T) == 2) rc = gemm256_bf16(head, epi, s);
+    else rc = gemm256_f32(head, epi, s);
+    if (rc != 0 || m_main == g.M) return rc;
+    const bool c32 = epi == GPT_EPI_RESADD || epi == GPT_EPI_STORE_F32 || epi == GPT_EPI_ACCUM_F32;
+    const bool aux32 = epi == GPT_EPI_RESADD;
+    GemmArgs<T> tail = g;
+    tail.M = g.M - m_main;
+    tail.A = g.A + (int64_t)m_main * g.lda;
+    tail.C = (char*)g.C + (int64_t)m_main * g.ldc * (c32 ? 4 : sizeof(T));
+    if (g.aux) tail.aux = (char*)g.aux + (int64_t)m_main * g.ldaux * (aux32 ? 4 : sizeof(T));
+    return dispatch_ring<T>(tail, epi, s);
   }
+  return dispatch_ring<T>(g, epi, s);
+}
+
+template <typename T>
+int dispatch_ring(const GemmArgs<T>& g, int epi, hipStream_t s) {
   switch (epi) {
     case GPT_EPI_STORE: return launch<T, GPT_EPI_STORE>(g, s);
     case GPT_EPI_GELU: return launch<T, GPT_EPI_GELU>(g, s);

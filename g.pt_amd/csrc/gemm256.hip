@@ -33,8 +33,12 @@ __device__ __forceinline__ u32x4 frag(const char* half, int row, int lc) {
   return *reinterpret_cast<const u32x4*>(half + row * RB + ((lc ^ ((row >> 1) & 7)) << 4));
 }
 
-template <typename T, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
+// SK (stream-K): the launch has one workgroup per CU and the tile x K-tile iteration space is cut into equal
+// contiguous spans, one per workgroup, so no CU idles in a last, partly filled round.  A span covers pieces of
+// (at most a few) tiles; each piece's partial sum is ADDED to the fp32 output with hardware float atomics, which is
+// why only the additive epilogues (RESADD in place, ACCUM_F32) can run this way.  `iters_per_wg` > 0 selects it.
+template <typename T, int EPI, bool SK>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g, int iters_per_wg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -44,11 +48,29 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   const int tiles_n = (g.N + 255) / 256;
-  const int m0 = (swz / tiles_n) * 256, n0 = (swz % tiles_n) * 256;
 
   constexpr int BK = RB / sizeof(T);
   constexpr int EPC = 16 / sizeof(T);
-  const int nk = g.K / BK;
+  const int nk_tile = g.K / BK;
+  const int fr = lane & 31, fh = lane >> 5;
+
+  int it = SK ? swz * iters_per_wg : 0;
+  const int it_end = SK ? min(it + iters_per_wg, tiles_n * ((g.M + 255) / 256) * nk_tile) : 0;
+  if (SK && it >= it_end) return;
+  for (;;) {
+  const int tile = SK ? it / nk_tile : swz;
+  const int kb = SK ? it - tile * nk_tile : 0;
+  const int nk = SK ? min(nk_tile - kb, it_end - it) : nk_tile;
+  // tile order inside an XCD's contiguous run: column groups of GROUP_N tiles, rows fastest across the group, so
+  // the ~32 tiles an XCD works on at once form a ~4 x 8 block (A and W panels both re-used from its 4 MiB L2)
+#ifndef GPT_GROUP_N
+#define GPT_GROUP_N 8
+#endif
+  constexpr int GROUP_N = GPT_GROUP_N;
+  const int tiles_m = (g.M + 255) / 256;
+  const int gb = tile / (tiles_m * GROUP_N), grem = tile - gb * (tiles_m * GROUP_N);
+  const int gw = min(GROUP_N, tiles_n - gb * GROUP_N);
+  const int m0 = (grem / gw) * 256, n0 = (gb * GROUP_N + grem % gw) * 256;
 
   // per-lane DMA source rows: this wave fills LDS rows [wid*16, wid*16+16) of every half-tile (2 pieces of 8 rows)
   const T* srcA[2][2];  // [half][piece]
@@ -61,10 +83,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
     for (int h = 0; h < 2; ++h) {
       int gm = m0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
       gm = gm < g.M ? gm : g.M - 1;
-      srcA[h][p] = g.A + (int64_t)gm * g.lda + lc * EPC;
+      srcA[h][p] = g.A + (int64_t)gm * g.lda + lc * EPC + (int64_t)kb * BK;
       int gn = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
       gn = gn < g.N ? gn : g.N - 1;
-      srcW[h][p] = g.W + (int64_t)gn * g.ldw + lc * EPC;
+      srcW[h][p] = g.W + (int64_t)gn * g.ldw + lc * EPC + (int64_t)kb * BK;
     }
   }
   auto dma = [&](const T* const (&src)[2], int kt, int slot) {
@@ -91,8 +113,28 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
       dma(srcA[1], t, 1);
     }
 
-  const int fr = lane & 31, fh = lane >> 5;
   auto mma = [&](const u32x4 (&a)[2][4], const u32x4 (&b)[4], int i0, int j) {
+#ifdef GPT_FAKE16
+    // timing experiment only (wrong numerics): the same FLOPs and operand traffic issued as 16x16x32 MFMAs
+    if constexpr (sizeof(T) == 2) {
+      typedef __attribute__((ext_vector_type(8))) float f32x8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ks += 2)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          f32x16 c = acc[i0 + i][j];
+          f32x4 q0 = __builtin_shufflevector(c, c, 0, 1, 2, 3), q1 = __builtin_shufflevector(c, c, 4, 5, 6, 7);
+          f32x4 q2 = __builtin_shufflevector(c, c, 8, 9, 10, 11), q3 = __builtin_shufflevector(c, c, 12, 13, 14, 15);
+          q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i][ks]), __builtin_bit_cast(bf16x8, b[ks]), q0, 0, 0, 0);
+          q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i][ks + 1]), __builtin_bit_cast(bf16x8, b[ks]), q1, 0, 0, 0);
+          q2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i][ks]), __builtin_bit_cast(bf16x8, b[ks + 1]), q2, 0, 0, 0);
+          q3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i][ks + 1]), __builtin_bit_cast(bf16x8, b[ks + 1]), q3, 0, 0, 0);
+          f32x8 lo = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7), hi = __builtin_shufflevector(q2, q3, 0, 1, 2, 3, 4, 5, 6, 7);
+          acc[i0 + i][j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+        }
+      return;
+    }
+#endif
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -182,16 +224,47 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
 #undef SEG_COMPUTE
   __syncthreads();
 
-  // epilogue through a private 4 KiB LDS patch per wave, 32 x 32 at a time (see gemm.hip)
-  float* patch = reinterpret_cast<float*>(smem + wid * PATCH_BYTES);
-  epilogue_wave<T, EPI, 4>(g, acc, patch, m0 + wr * 128, n0 + wc * 64, lane);
+  if constexpr (SK) {
+    // partial sums straight from the accumulator layout: a wave instruction adds to two full 128-byte lines
+    // (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)); the piece that starts the tile adds the bias
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wc * 64 + j * 32 + fr;
+      if (n >= g.N) continue;
+      const float bias = (kb == 0 && g.bias) ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+          if (m < g.M) unsafeAtomicAdd((float*)g.C + (int64_t)m * g.ldc + n, acc[i][j][e] + bias);
+        }
+    }
+    it += nk;
+    if (it >= it_end) break;
+  } else {
+    // epilogue through a private LDS patch per wave, 32 x 32 at a time (see gemm_common.h)
+    float* patch = reinterpret_cast<float*>(smem + wid * PATCH_BYTES);
+    epilogue_wave<T, EPI, 4>(g, acc, patch, m0 + wr * 128, n0 + wc * 64, lane);
+    break;
+  }
+  }
 }
 
-template <typename T, int EPI>
+int n_cus() {
+  static const int n = [] {
+    int dev = 0, v = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+    return v > 0 ? v : 256;
+  }();
+  return n;
+}
+
+template <typename T, int EPI, bool SK>
 int launch256(const GemmArgs<T>& g, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm256_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+    if (hipFuncSetAttribute((const void*)gemm256_kernel<T, EPI, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
         hipSuccess) {
       gpt_set_error("gpt_gemm_nt: cannot reserve %d bytes of LDS", LDS_BYTES);
       return -1;
@@ -199,9 +272,16 @@ int launch256(const GemmArgs<T>& g, hipStream_t s) {
     attr_set = true;
   }
   const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+  int grid = tiles, ipw = 0;
+  if (SK) {
+    const int total = tiles * (g.K / (RB / (int)sizeof(T)));
+    grid = n_cus();
+    ipw = (total + grid - 1) / grid;
+    grid = (total + ipw - 1) / ipw;
+  }
   const bool rec = g_prof.on && g_prof.n < GemmProf::CAP;
   if (rec) (void)hipEventRecord(g_prof.ev[g_prof.n][0], s);
-  hipLaunchKernelGGL((gemm256_kernel<T, EPI>), dim3(tiles), dim3(512), LDS_BYTES, s, g);
+  hipLaunchKernelGGL((gemm256_kernel<T, EPI, SK>), dim3(grid), dim3(512), LDS_BYTES, s, g, ipw);
   if (rec) {
     (void)hipEventRecord(g_prof.ev[g_prof.n][1], s);
     g_prof.flops[g_prof.n++] = 2.0 * g.M * g.N * g.K;
@@ -209,16 +289,35 @@ int launch256(const GemmArgs<T>& g, hipStream_t s) {
   return gpt_launch_status("gpt_gemm_nt");
 }
 
+// Stream-K pays when the additive epilogue allows it, the data-parallel launch would leave its last round badly
+// filled, and every workgroup still gets a few K-tiles.  bf16 only: the exact-fp32 parity mode stays order-deterministic.
+template <typename T>
+bool use_stream_k(const GemmArgs<T>& g, int epi) {
+  static const bool enabled = [] {
+    // OFF by default: measured slower on every shape of this model (r01: proj 70 -> 154 us, fc2 189 -> 251 us, the
+    // B=1024 wgrads 544 -> 626 us): ~65 k float atomics per piece cost more than the idle CUs they recover
+    const char* e = getenv("GPT_GEMM_STREAMK");
+    return e && atoi(e) != 0;
+  }();
+  if (!enabled || sizeof(T) != 2) return false;
+  if (!(epi == GPT_EPI_ACCUM_F32 || (epi == GPT_EPI_RESADD && g.aux == nullptr))) return false;
+  const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256), n = n_cus();
+  const int rounds = (tiles + n - 1) / n;
+  const int total = tiles * (g.K / (RB / (int)sizeof(T)));
+  return tiles * 100 < rounds * n * 88 && total >= 6 * n;
+}
+
 template <typename T>
 int dispatch256(const GemmArgs<T>& g, int epi, hipStream_t s) {
+  if (use_stream_k(g, epi)) return launch256<T, GPT_EPI_ACCUM_F32, true>(g, s);
   switch (epi) {
-    case GPT_EPI_STORE: return launch256<T, GPT_EPI_STORE>(g, s);
-    case GPT_EPI_GELU: return launch256<T, GPT_EPI_GELU>(g, s);
-    case GPT_EPI_RESADD: return launch256<T, GPT_EPI_RESADD>(g, s);
-    case GPT_EPI_STORE_F32: return launch256<T, GPT_EPI_STORE_F32>(g, s);
-    case GPT_EPI_GELU_AUX: return launch256<T, GPT_EPI_GELU_AUX>(g, s);
-    case GPT_EPI_DGELU: return launch256<T, GPT_EPI_DGELU>(g, s);
-    case GPT_EPI_ACCUM_F32: return launch256<T, GPT_EPI_ACCUM_F32>(g, s);
+    case GPT_EPI_STORE: return launch256<T, GPT_EPI_STORE, false>(g, s);
+    case GPT_EPI_GELU: return launch256<T, GPT_EPI_GELU, false>(g, s);
+    case GPT_EPI_RESADD: return launch256<T, GPT_EPI_RESADD, false>(g, s);
+    case GPT_EPI_STORE_F32: return launch256<T, GPT_EPI_STORE_F32, false>(g, s);
+    case GPT_EPI_GELU_AUX: return launch256<T, GPT_EPI_GELU_AUX, false>(g, s);
+    case GPT_EPI_DGELU: return launch256<T, GPT_EPI_DGELU, false>(g, s);
+    case GPT_EPI_ACCUM_F32: return launch256<T, GPT_EPI_ACCUM_F32, false>(g, s);
   }
   gpt_set_error("gpt_gemm_nt: unknown epilogue %d", epi);
   return -1;
@@ -227,6 +326,7 @@ int dispatch256(const GemmArgs<T>& g, int epi, hipStream_t s) {
 }  // namespace
 
 int gemm256_bf16(const GemmArgs<bf16_t>& g, int epi, hipStream_t s) { return dispatch256<bf16_t>(g, epi, s); }
+bool gemm256_stream_k(const GemmArgs<bf16_t>& g, int epi) { return use_stream_k<bf16_t>(g, epi); }
 int gemm256_f32(const GemmArgs<float>& g, int epi, hipStream_t s) { return dispatch256<float>(g, epi, s); }
 
 }  // namespace gemmk

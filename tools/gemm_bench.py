@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--d", type=int, default=1536)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--rounds", type=int, default=20)
+    ap.add_argument("--shapes", nargs="*", default=None)
     args = ap.parse_args()
     code = L.dtype_code(args.dtype)
     td = L.torch_dtype(code)
@@ -25,6 +26,11 @@ def main():
     shapes = [("qkv", M, 3 * d, d, L.EPI_STORE), ("proj", M, d, d, L.EPI_RESADD), ("fc1", M, 4 * d, d, L.EPI_GELU),
               ("fc2", M, d, 4 * d, L.EPI_RESADD), ("sq4096", 4096, 4096, 4096, L.EPI_STORE),
               ("sq8192", 8192, 8192, 8192, L.EPI_STORE)]
+    if args.shapes:                      # "name:M:N:K[:epi]" ...
+        shapes = []
+        for spec in args.shapes:
+            f = spec.split(":")
+            shapes.append((f[0], int(f[1]), int(f[2]), int(f[3]), int(f[4]) if len(f) > 4 else L.EPI_STORE))
     lib = L.lib()
     bufs = []
     for name, m, n, k, epi in shapes:
@@ -52,11 +58,12 @@ def main():
         ts = sorted(ev[r][i][0].elapsed_time(ev[r][i][1]) for r in range(args.rounds))
         med, mn = ts[len(ts) // 2], ts[0]
         fl = 2.0 * m * n * k
-        if i < 4:
+        if i < 4 and not args.shapes:
             tot_t += med
             tot_f += fl
         print(f"{name:8s} M={m:6d} N={n:5d} K={k:5d}  median {med * 1e3:8.1f} us  {fl / med / 1e9:7.1f} TF   min {mn * 1e3:8.1f} us {fl / mn / 1e9:7.1f} TF")
-    print(f"layer total (4 GEMMs): {tot_t * 1e3:.1f} us  {tot_f / tot_t / 1e9:.1f} TF")
+    if not args.shapes:
+        print(f"layer total (4 GEMMs): {tot_t * 1e3:.1f} us  {tot_f / tot_t / 1e9:.1f} TF")
 
 
 if __name__ == "__main__":
