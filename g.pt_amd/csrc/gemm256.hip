@@ -175,7 +175,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g, int iter
     __builtin_amdgcn_s_setprio(0);           \
   } while (0)
 
-  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // A-h0(0), W-h0(0) landed (6 half-tiles issued after them)
+  // the first two half-tiles (h0 of both operands of K-tile 0) have landed: all but the 6 (one K-tile: 2) half-tiles issued after them
+  if (nk >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   if (wr == 1) __builtin_amdgcn_s_barrier();           // group 1 runs one barrier behind group 0
 
   for (int kt = 0; kt < nk; ++kt) {

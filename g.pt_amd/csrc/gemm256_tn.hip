@@ -1,0 +1,252 @@
+// 256 x 256 block-tile bf16 MFMA GEMM with BOTH operands contracted over their ROW index ("TN"):
+//     C[I, J] (epilogue)= sum_r P[r, i] * Q[r, j]          P: [R, I] row-major, Q: [R, J] row-major
+// This is the weight gradient dW[n_out, k_in] = dY^T . X of every Linear of the trunk (autograd of
+// Gpt/models/transformer.py:38-40,50,63-65): P = dY [B*T, n_out], Q = X [B*T, k_in] are consumed exactly as the
+// forward / backward kernels wrote them - no transposed copies of the activations.
+//
+// Same pipeline as gemm256.hip (8 waves as 2 x 4 of 128 x 64, two 64-KiB K-tile buffers of four 16-KiB half-tiles,
+// four phases per K-tile, LDS-DMA refills with counted vmcnt, two wave groups one barrier apart).  What differs:
+//  * a K-tile is 64 ROWS r of the operands; a half-tile holds, for each of them, 128 CONTIGUOUS columns of the block
+//    tile (full 256-byte runs for the LDS-DMA) = 64 LDS rows of 256 bytes; a wave therefore owns output rows
+//    {128 hi + 64 wr + [0, 64)} and columns {128 hj + 32 wc + [0, 32)} for the halves hi, hj = 0, 1;
+//  * the MFMA operands (8 consecutive r for one column) are gathered with ds_read_b64_tr_b16, gfx950's transposing
+//    LDS read: a 16-lane group reads a 4-row x 16-column block and every lane receives one COLUMN of it, so two
+//    reads give a lane its 8 k-values.  16-byte chunk c of LDS row r is stored at chunk c ^ ((r & 3) << 2): the four
+//    rows of a block then sit in four different 64-byte bank groups and the read is conflict-free.
+// Needs R % 64 == 0, I % 256 == 0, J % 256 == 0 (the host falls back to transposes + the NT kernel otherwise).
+#include "gemm_common.h"
+
+namespace gemmk {
+namespace {
+
+constexpr int TRB = 256;             // bytes per LDS row (128 bf16 columns)
+constexpr int THALF = 64 * TRB;      // 16 KiB half-tile: 64 r-rows
+constexpr int TBUF = 4 * THALF;      // P-h0 | P-h1 | Q-h0 | Q-h1
+constexpr int TLDS_BYTES = 2 * TBUF;  // 128 KiB
+
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s* lds_v4s_ptr;
+
+// the 8 k-values (rows r0 .. r0+7 of the half-tile, r0 = 16 ks + 8 (lane >> 5)) of this lane's column
+__device__ __forceinline__ u32x4 tr_frag(const char* base_lo, int ks) {
+#ifdef GPT_TN_EXP_B128   // timing experiment (wrong numerics): one ds_read_b128 instead of the two transposing reads
+  return *reinterpret_cast<const u32x4*>((const char*)((uintptr_t)(base_lo + ks * 16 * TRB) & ~(uintptr_t)15));
+#endif
+  // base_lo already holds this lane's row (8 (g >> 1) + q) * TRB + swizzled chunk + 8 (p & 1); rows +4 are 4 TRB on
+  const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(base_lo + ks * 16 * TRB));
+  const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(base_lo + ks * 16 * TRB + 4 * TRB));
+  typedef short v8s __attribute__((ext_vector_type(8)));
+  const v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);   // register concatenation, no VALU
+  const u32x4 out = __builtin_bit_cast(u32x4, both);
+  return out;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(GemmArgs<bf16_t> g) {
+  using T = bf16_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  // column groups of 8 tiles, rows fastest across the group (see gemm256.hip): both strips re-used from the XCD's L2
+  constexpr int GROUP_N = 8;
+  const int tiles_n = g.N / 256, tiles_m = g.M / 256;
+  const int gb = tile / (tiles_m * GROUP_N), grem = tile - gb * (tiles_m * GROUP_N);
+  const int gw = min(GROUP_N, tiles_n - gb * GROUP_N);
+  const int m0 = (grem / gw) * 256, n0 = (gb * GROUP_N + grem % gw) * 256;   // output rows (P columns) / columns (Q columns)
+  const int nk = g.K / 64;
+
+  // per-lane DMA sources: this wave fills LDS rows [wid*8, wid*8+8) of every half-tile (2 pieces of 4 rows);
+  // lane -> (row = lane >> 4, chunk = lane & 15) of the piece, the chunk's logical position un-swizzled
+  const T* srcP[2][2];  // [half][piece]
+  const T* srcQ[2][2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int lr = wid * 8 + p * 4 + (lane >> 4);
+    const int lc = (lane & 15) ^ ((lr & 3) << 2);          // logical 16-byte chunk (8 columns) of the 128-column row
+    const int e = lc * 8;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#ifdef GPT_TN_EXP_SRC    // timing experiment (wrong numerics): the NT kernel's source pattern (8 rows x 128 B per instruction)
+      srcP[h][p] = g.A + (int64_t)(m0 % 64 + wid * 16 + p * 8 + (lane >> 3)) * g.lda + (lane & 7) * 8 + h * 64;
+      srcQ[h][p] = g.W + (int64_t)(n0 % 64 + wid * 16 + p * 8 + (lane >> 3)) * g.ldw + (lane & 7) * 8 + h * 64;
+#else
+      srcP[h][p] = g.A + (int64_t)lr * g.lda + m0 + h * 128 + e;
+      srcQ[h][p] = g.W + (int64_t)lr * g.ldw + n0 + h * 128 + e;
+#endif
+    }
+  }
+  const int64_t stepP = 64 * g.lda, stepQ = 64 * g.ldw;
+  auto dma = [&](const T* const (&src)[2], int64_t step, int kt, int slot) {
+    char* dst = smem + (kt & 1) * TBUF + slot * THALF + wid * 2048;
+    __builtin_amdgcn_global_load_lds((gptr_t)(src[0] + kt * step), (lptr_t)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(src[1] + kt * step), (lptr_t)(dst + 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+    if (t < nk) {
+      dma(srcP[0], stepP, t, 0);
+      dma(srcQ[0], stepQ, t, 2);
+      dma(srcQ[1], stepQ, t, 3);
+      dma(srcP[1], stepP, t, 1);
+    }
+
+  // transposed-read addresses: 16-lane group gq reads the block rows 8 (gq >> 1) + q, columns e0 + 16 (gq & 1) + 4 p
+  const int gq = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  const int trow = 8 * (gq >> 1) + tq;
+  auto tr_off = [&](int e0) {
+    const int e = e0 + 16 * (gq & 1) + 4 * tp;
+    return trow * TRB + (((e >> 3) ^ (tq << 2)) << 4) + 8 * (tp & 1);
+  };
+  const int offP[2] = {tr_off(wr * 64), tr_off(wr * 64 + 32)};
+  const int offQ = tr_off(wc * 32);
+
+  auto mma = [&](const u32x4 (&a)[2][4], const u32x4 (&b)[4], int i0, int j) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i][ks]),
+                                                                __builtin_bit_cast(bf16x8, b[ks]), acc[i0 + i][j], 0, 0, 0);
+  };
+#define SEG_WAIT()                                                          \
+  do {                                                                      \
+    if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   \
+  } while (0)
+#define SEG_BARRIER()                        \
+  do {                                       \
+    __builtin_amdgcn_sched_barrier(0);       \
+    __builtin_amdgcn_s_barrier();            \
+    __builtin_amdgcn_sched_barrier(0);       \
+  } while (0)
+#define SEG_READS_DONE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define SEG_COMPUTE(A_, B_, I0, J)           \
+  do {                                       \
+    SEG_BARRIER();                           \
+    __builtin_amdgcn_s_setprio(1);           \
+    mma(A_, B_, I0, J);                      \
+    __builtin_amdgcn_s_setprio(0);           \
+  } while (0)
+
+  // the first two half-tiles (h0 of both operands of K-tile 0) have landed: all but the 6 (one K-tile: 2) half-tiles issued after them
+  if (nk >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if (wr == 1) __builtin_amdgcn_s_barrier();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* buf = smem + (kt & 1) * TBUF;
+    const bool steady = kt + 2 < nk;
+    u32x4 a[2][4], b0[4], b1[4];
+    // ---- p0: P-h0 x Q-h0
+    SEG_WAIT();
+    SEG_BARRIER();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) b0[ks] = tr_frag(buf + 2 * THALF + offQ, ks);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a[i][ks] = tr_frag(buf + offP[i], ks);
+    if (kt >= 1 && kt + 1 < nk) dma(srcP[1], stepP, kt + 1, 1);
+    SEG_READS_DONE();
+    SEG_COMPUTE(a, b0, 0, 0);
+    // ---- p1: P-h0 x Q-h1
+    SEG_WAIT();
+    SEG_BARRIER();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) b1[ks] = tr_frag(buf + 3 * THALF + offQ, ks);
+    if (steady) dma(srcP[0], stepP, kt + 2, 0);
+    SEG_READS_DONE();
+    SEG_COMPUTE(a, b1, 0, 1);
+    // ---- p2: P-h1 x Q-h1
+    SEG_BARRIER();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a[i][ks] = tr_frag(buf + THALF + offP[i], ks);
+    if (steady) dma(srcQ[0], stepQ, kt + 2, 2);
+    SEG_READS_DONE();
+    SEG_COMPUTE(a, b1, 2, 1);
+    // ---- p3: P-h1 x Q-h0, both in registers
+    SEG_WAIT();
+    SEG_BARRIER();
+    if (steady) dma(srcQ[1], stepQ, kt + 2, 3);
+    SEG_COMPUTE(a, b0, 2, 0);
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+#undef SEG_WAIT
+#undef SEG_BARRIER
+#undef SEG_READS_DONE
+#undef SEG_COMPUTE
+  __syncthreads();
+
+  // epilogue straight from the accumulator layout (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)):
+  // the output is fp32, so every wave instruction reads / writes two full 128-byte lines
+  const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float* c = (float*)g.C + (int64_t)(m0 + (i >> 1) * 128 + wr * 64 + (i & 1) * 32 + 4 * fh) * g.ldc + n0 + j * 128 + wc * 32 + fr;
+      if constexpr (EPI == GPT_EPI_ACCUM_F32) {
+        float old[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) old[e] = c[(int64_t)((e & 3) + 8 * (e >> 2)) * g.ldc];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c[(int64_t)((e & 3) + 8 * (e >> 2)) * g.ldc] = old[e] + acc[i][j][e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c[(int64_t)((e & 3) + 8 * (e >> 2)) * g.ldc] = acc[i][j][e];
+      }
+    }
+}
+
+template <int EPI>
+int launch_tn(const GemmArgs<bf16_t>& g, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm256_tn_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, TLDS_BYTES) !=
+        hipSuccess) {
+      gpt_set_error("gpt_gemm_tn: cannot reserve %d bytes of LDS", TLDS_BYTES);
+      return -1;
+    }
+    attr_set = true;
+  }
+  const int tiles = (g.M / 256) * (g.N / 256);
+  const bool rec = g_prof.on && g_prof.n < GemmProf::CAP;
+  if (rec) (void)hipEventRecord(g_prof.ev[g_prof.n][0], s);
+  hipLaunchKernelGGL((gemm256_tn_kernel<EPI>), dim3(tiles), dim3(512), TLDS_BYTES, s, g);
+  if (rec) {
+    (void)hipEventRecord(g_prof.ev[g_prof.n][1], s);
+    g_prof.flops[g_prof.n++] = 2.0 * g.M * g.N * g.K;
+  }
+  return gpt_launch_status("gpt_gemm_tn");
+}
+
+}  // namespace
+}  // namespace gemmk
+
+extern "C" int gpt_gemm_tn(const void* P, int64_t ldp, const void* Q, int64_t ldq, float* C, int64_t ldc, int I, int J, int R,
+                           int accumulate, void* stream) {
+  using namespace gemmk;
+  GPT_REQUIRE(P && Q && C, "gpt_gemm_tn: null operand");
+  GPT_REQUIRE(I > 0 && J > 0 && R > 0 && I % 256 == 0 && J % 256 == 0 && R % 64 == 0,
+              "gpt_gemm_tn: need I %% 256 == 0, J %% 256 == 0, R %% 64 == 0 (got I=%d J=%d R=%d)", I, J, R);
+  GPT_REQUIRE(ldp >= I && ldq >= J && ldc >= J && ldp % 8 == 0 && ldq % 8 == 0 && ldc % 4 == 0, "gpt_gemm_tn: bad leading dimensions");
+  GPT_REQUIRE(((uintptr_t)P % 16) == 0 && ((uintptr_t)Q % 16) == 0 && ((uintptr_t)C % 16) == 0, "gpt_gemm_tn: operands must be 16-byte aligned");
+  GemmArgs<bf16_t> g{(const bf16_t*)P, (const bf16_t*)Q, nullptr, C, nullptr, ldp, ldq, ldc, 0, I, J, R};
+  return accumulate ? launch_tn<GPT_EPI_ACCUM_F32>(g, (hipStream_t)stream) : launch_tn<GPT_EPI_STORE_F32>(g, (hipStream_t)stream);
+}

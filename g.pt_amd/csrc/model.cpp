@@ -3,6 +3,7 @@
 //   Gpt.forward                     Gpt/models/transformer.py:440-464 (+ GPT.forward :302-314, Block :69-72)
 //   p_sample_loop_progressive       Gpt/diffusion/gaussian_diffusion.py:458-505
 #include "common.h"
+#include <stdlib.h>
 
 #define CHECK(call)             \
   do {                          \
@@ -137,7 +138,14 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
   auto lay = [&](void* base, int l, size_t width) { return (void*)((char*)base + (size_t)l * Mmax * width * es); };
   auto stat = [&](int idx, int which) { return ws->stats + ((size_t)idx * 2 + which) * Mmax; };
   // dW[n_out, k_in] += dY^T . X through the NT kernel: both operands transposed to [*, Mp] (K = rows, zero padded)
+  static const bool use_tn = [] {
+    const char* e = getenv("GPT_WGRAD_TN");   // 0: always transpose + NT kernel (cross-check of the TN kernel)
+    return !e || atoi(e) != 0;
+  }();
   auto wgrad = [&](const void* dY, int n_out, const void* X, int k_in, float* gW) -> int {
+    // the TN kernel only has 256 x 256 tiles: with few of them (d x d weights) transposes + the finer ring kernels win (r01 bench)
+    if (use_tn && dt == GPT_BF16 && M % 64 == 0 && n_out % 256 == 0 && k_in % 256 == 0 && (n_out / 256) * (k_in / 256) >= 96)
+      return gpt_gemm_tn(dY, n_out, X, k_in, gW, k_in, n_out, k_in, M, 1, stream);
     CHECK(gpt_transpose(dt, dY, bw->tA, M, n_out, Mp, stream));
     CHECK(gpt_transpose(dt, X, bw->tB, M, k_in, Mp, stream));
     return gpt_gemm_nt(dt, bw->tA, Mp, bw->tB, Mp, nullptr, gW, k_in, nullptr, 0, n_out, k_in, (int)Mp, GPT_EPI_ACCUM_F32, stream);

@@ -47,6 +47,13 @@ int gpt_gemm_nt(int dtype, const void* A, int64_t lda, const void* W, int64_t ld
                 void* C, int64_t ldc, void* aux, int64_t ldaux, int M, int N, int K, int epilogue,
                 void* stream);
 
+/* C[I, J] (+)= P[R, I]^T . Q[R, J]: bf16 operands contracted over their ROW index, fp32 output (accumulate != 0:
+ * C += ...).  The weight gradient dW = dY^T . X that autograd derives for every nn.Linear of the trunk
+ * (Gpt/models/transformer.py:38-40, 50, 63-65), reading dY [B*T, n_out] and X [B*T, k_in] as they lie in memory
+ * (transposing LDS reads, ds_read_b64_tr_b16).  I % 256 == 0, J % 256 == 0, R % 64 == 0; ldp, ldq % 8 == 0. */
+int gpt_gemm_tn(const void* P, int64_t ldp, const void* Q, int64_t ldq, float* C, int64_t ldc, int I, int J, int R,
+                int accumulate, void* stream);
+
 /* Measurement aid (bench.py roofline pass; no counterpart in the reference): while enabled, every gpt_gemm_nt
  * launch is bracketed by two HIP events recorded on its own stream (at most 4096 launches per enable);
  * collect waits for them and returns the summed kernel time, the summed algorithmic FLOPs (2 M N K) and the

@@ -289,3 +289,54 @@ def test_two_rank_step_equals_full_batch(tmp_path):
         if k.endswith("attn.key.bias"):
             continue
         assert float((p.detach().cpu() - got[k]).abs().max()) < 5e-5 * max(1.0, float(got[k].abs().max())), k
+
+
+@pytest.mark.parametrize("I,J,R", [(256, 256, 64), (512, 768, 832), (1536, 256, 3328)])
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_gemm_tn_matches_torch(I, J, R, accumulate):
+    """C (+)= P^T Q with both bf16 operands read as stored (transposing LDS reads) against an fp64 product."""
+    g = torch.Generator().manual_seed(I + J + R)
+    P = torch.randn(R, I, generator=g).bfloat16().to(DEV)
+    Q = torch.randn(R, J, generator=g).bfloat16().to(DEV)
+    C0 = torch.randn(I, J, generator=g).to(DEV)
+    C = C0.clone()
+    L.check(L.lib().gpt_gemm_tn(L.ptr(P), I, L.ptr(Q), J, L.ptr(C), J, I, J, R, accumulate, L.stream()), "gpt_gemm_tn")
+    ref = P.double().t() @ Q.double() + (C0.double() if accumulate else 0)
+    assert float((C.double() - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+    # rejected shapes: no launch
+    assert L.lib().gpt_gemm_tn(L.ptr(P), I, L.ptr(Q), J, L.ptr(C), J, I, J, R - 32, 0, L.stream()) != 0
+
+
+def test_wgrad_tn_path_equals_transpose_path():
+    """The weight gradients through the TN kernel (cifar_small: d = 256, B*T % 64 == 0) equal the transpose + NT route."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from tests.test_hip_parity import build, DEV
+from tests.cases import make_inputs
+import gpt_amd
+m, plan, sd = build("cifar_small", "bf16", seed=6)
+m.train()
+diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
+_, _, lt, lp, xp = (v.to(DEV) for v in make_inputs("cifar_small", B=32, seed=7))
+g = torch.Generator().manual_seed(8)
+x1 = xp + 0.1 * torch.randn(xp.shape, generator=g).to(DEV)
+t = torch.randint(0, 1000, (32,), generator=g).to(DEV)
+noise = torch.randn(xp.shape, generator=g).to(DEV)
+diff.training_losses(m, x1, t, model_kwargs=dict(loss_target=lt, loss_prev=lp, x_prev=xp), noise=noise)["loss"].mean().backward()
+torch.save({k: p.grad.cpu() for k, p in m.named_parameters()}, sys.argv[1])
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for flag in ("1", "0"):
+            path = os.path.join(td, f"g{flag}.pt")
+            env = dict(os.environ, GPT_WGRAD_TN=flag)
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=200)
+            outs.append(torch.load(path, weights_only=True))
+    for k in outs[0]:
+        a, b = outs[0][k], outs[1][k]
+        assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-12) + 1e-9, k
