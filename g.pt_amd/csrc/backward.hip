@@ -3,9 +3,10 @@
 // and a small strided fp32 GEMM for the ragged encoder / decoder gradients.
 // They implement what autograd derives for Gpt/models/transformer.py:34-51 (attention), :69-72 (Block),
 // :215-242 (encoder / decoder) in the reference; parity is pinned by the gradient fixtures g6_training_*.
-#include "common.h"
+#include "gemm_common.h"
 
 namespace {
+using gemmk::load8;
 
 // ------------------------------------------------------------------------------------------ LayerNorm backward
 // One wave per row, the row held in registers (lane l owns columns 256 ch + 4 l .. + 3 of chunk ch < NCH).
@@ -32,8 +33,10 @@ __device__ __forceinline__ void store_row4(bf16_t* p, f32x4 v) {
   *reinterpret_cast<uint2*>(p) = u;
 }
 
+constexpr int LNB_WAVES = 8;   // waves per workgroup: few workgroups (the dgamma / dbeta flush is one fp32 atomic per column per
+                               // workgroup, and atomics are slow) but enough waves per CU to hide the row loads
 template <typename DyT, typename OutT, int NCH>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const DyT* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ resid,
                                                             float* __restrict__ gout, OutT* __restrict__ gout_t,
@@ -41,7 +44,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restric
                                                             int d, int rows_per_block) {
   extern __shared__ float red[];  // [2][d] per-workgroup partial dgamma / dbeta
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int c = threadIdx.x; c < 2 * d; c += 256) red[c] = 0.f;
+  for (int c = threadIdx.x; c < 2 * d; c += LNB_WAVES * 64) red[c] = 0.f;
   __syncthreads();
   f32x4 gam[NCH], pg[NCH], pb[NCH];
 #pragma unroll
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restric
   const int row_begin = blockIdx.x * rows_per_block;
   const int row_end = min(rows, row_begin + rows_per_block);
   const float inv_d = 1.0f / (float)d;
-  for (int row = row_begin + wave; row < row_end; row += 4) {
+  for (int row = row_begin + wave; row < row_end; row += LNB_WAVES) {
     const float mu = mean[row], rs = rstd[row];
     const int64_t base = (int64_t)row * d;
     f32x4 xh[NCH], dyv[NCH];
@@ -107,23 +110,46 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restric
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < d; c += 256) {
+  for (int c = threadIdx.x; c < d; c += LNB_WAVES * 64) {
     unsafeAtomicAdd(dgamma + c, red[c]);          // hardware global_atomic_add_f32 (plain atomicAdd is a CAS loop)
     unsafeAtomicAdd(dbeta + c, red[d + c]);
   }
 }
 
 // ------------------------------------------------------------------------------------------ column sums
-// out[c] += sum_r X[r, c]   (X: rows x cols, leading dimension ld)
+// out[c] += sum_r X[r, c]   (X: rows x cols, leading dimension ld).  A workgroup owns 256 columns x one row range:
+// thread (cg = tid & 31, rl = tid >> 5) sums 8 adjacent columns (one 16-byte load of bf16, two of fp32) over rows
+// rl, rl + 8, ...; the 8 row lanes meet in LDS and one hardware fp32 atomic per column leaves the workgroup.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int64_t ld, float* __restrict__ out, int rows,
-                                                     int cols, int rows_per_block) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
+                                                     int cols, int rows_per_block, int vec) {
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * 256 + cg * 8;
   const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-  float s = 0.f;
-  for (int r = r0; r < r1; ++r) s += elem<T>::load(X + (int64_t)r * ld + c);
-  unsafeAtomicAdd(out + c, s);
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (vec && c0 + 8 <= cols) {
+    for (int r = r0 + rl; r < r1; r += 8) {
+      float4 a, b;
+      load8<T>(X + (int64_t)r * ld + c0, a, b);
+      s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
+      s[4] += b.x; s[5] += b.y; s[6] += b.z; s[7] += b.w;
+    }
+  } else {
+    for (int r = r0 + rl; r < r1; r += 8)
+      for (int j = 0; j < 8; ++j)
+        if (c0 + j < cols) s[j] += elem<T>::load(X + (int64_t)r * ld + c0 + j);
+  }
+  __shared__ float red[8][256 + 8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[rl][cg * 8 + j] = s[j];
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+    unsafeAtomicAdd(out + c, t);
+  }
 }
 
 // ------------------------------------------------------------------------------------------ small strided GEMM
@@ -425,9 +451,11 @@ extern "C" int gpt_layernorm_bwd(const void* dy, int dy_dtype, const float* x, c
                                  float* dgamma, float* dbeta, int rows, int d, void* stream) {
   GPT_REQUIRE(dy && x && mean && rstd && gamma && gout && dgamma && dbeta, "gpt_layernorm_bwd: null operand");
   GPT_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 3072, "gpt_layernorm_bwd: bad sizes (need d %% 4 == 0, d <= 3072)");
-  const int blocks = rows < 1024 ? (rows + 3) / 4 : 256;
+  // every workgroup ends with one atomic per column on the SAME 2d addresses: their number, not the streaming, sets the tail
+  int blocks = (rows + LNB_WAVES - 1) / LNB_WAVES;
+  blocks = blocks > 256 ? 256 : blocks;
   const int rpb = (rows + blocks - 1) / blocks;
-  const dim3 grid((rows + rpb - 1) / rpb), block(256);
+  const dim3 grid((rows + rpb - 1) / rpb), block(LNB_WAVES * 64);
   const size_t lds = 2 * (size_t)d * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   const bool dyb = dy_dtype == GPT_BF16, ob = gout_t_dtype == GPT_BF16;
@@ -455,12 +483,18 @@ extern "C" int gpt_layernorm_bwd(const void* dy, int dy_dtype, const float* x, c
 extern "C" int gpt_colsum(int dtype, const void* X, int64_t ld, float* out, int rows, int cols, void* stream) {
   GPT_REQUIRE(dtype == GPT_F32 || dtype == GPT_BF16, "gpt_colsum: bad dtype %d", dtype);
   GPT_REQUIRE(X && out && rows > 0 && cols > 0 && ld >= cols, "gpt_colsum: bad arguments");
-  const int rpb = rows < 64 ? rows : (rows + 63) / 64;
+  // enough workgroups to fill the chip (2-3 per CU), at least 64 rows each so the LDS meet / atomics stay amortised
+  const int col_blocks = (cols + 255) / 256;
+  int row_blocks = (768 + col_blocks - 1) / col_blocks;
+  if (row_blocks > (rows + 63) / 64) row_blocks = (rows + 63) / 64;
+  const int rpb = (rows + row_blocks - 1) / row_blocks;
   const dim3 grid((cols + 255) / 256, (rows + rpb - 1) / rpb), block(256);
+  const int esz = dtype == GPT_BF16 ? 2 : 4;
+  const int vec = ((uintptr_t)X % 16 == 0) && ((ld * esz) % 16 == 0);
   if (dtype == GPT_BF16)
-    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)X, ld, out, rows, cols, rpb);
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)X, ld, out, rows, cols, rpb, vec);
   else
-    hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)X, ld, out, rows, cols, rpb);
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)X, ld, out, rows, cols, rpb, vec);
   return gpt_launch_status("gpt_colsum");
 }
 
