@@ -222,7 +222,8 @@ int dispatch(const GemmArgs<T>& g, int epi, hipStream_t s) {
   const int tiles256 = ((g.M + 255) / 256) * ((g.N + 255) / 256);
   bool sk = false;
   if constexpr (sizeof(T) == 2) sk = tile_mode() == 0 && tiles256 >= 16 && gemm256_stream_k(g, epi);
-  if (tile_mode() == 3 || (tile_mode() == 0 && tiles256 >= 128) || sk) {
+  const bool k_ok = g.K % (128 / (int)sizeof(T)) == 0;   // the 256 x 256 kernel moves 128 bytes of K per row and K-tile
+  if (k_ok && (tile_mode() == 3 || (tile_mode() == 0 && tiles256 >= 128) || sk)) {
     const int m_main = tile_mode() == 0 && !sk ? split_rows(g) : g.M;
     GemmArgs<T> head = g;
     head.M = m_main;

@@ -281,6 +281,15 @@ int gpt_sample_loop(const gpt_model_t* m, const gpt_workspace_t* ws, float* x, c
                     const float* noise, uint64_t seed, int64_t* t_model, int64_t* t_index, float* model_out,
                     float* noise_buf, int B, void* stream);
 
+/* Quality metric of sampled MNIST-MLP parameter vectors, all B nets at once (replaces moduleify + the per-net loop
+ * of batch_test_fn, Gpt/vis.py:398-413, 539-570, around test_epoch, data_gen/train_mnist.py:324-332).
+ * H: fp32 [B * hidden, ldh] = fc1 pre-activations WITHOUT bias, image index contiguous (one gpt_gemm_nt over the
+ * fc1 weights of every net); nets: fp32 [B, net_stride] flat vectors with fc1.bias / fc2.weight / fc2.bias at the
+ * given element offsets; labels: int64 [n_img].  loss[b] = mean cross-entropy, err[b] = 100 * mean(argmax != label).
+ * hidden <= 64, classes <= 16. */
+int gpt_mlp_head(const float* H, int64_t ldh, const float* nets, int64_t net_stride, int off_b1, int off_w2, int off_b2,
+                 const int64_t* labels, float* loss, float* err, int B, int hidden, int classes, int n_img, void* stream);
+
 /* ---- optimizer step on one flat fp32 parameter arena (training-step harness, main.py:66-74) ----------------------
  * A segment is one named parameter: `count` elements at element offset `start` of the arenas (starts are multiples
  * of 4 elements; the gap up to the next start is zero padding).  decay: 1 = AdamW weight-decay group (Linear

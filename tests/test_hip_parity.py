@@ -302,3 +302,56 @@ def test_permutation_maps_bit_exact(golden):
         pa, pb = P.random_permute_batch([a.to(DEV), b.to(DEV)], arch, range(16))
         ia = torch.from_numpy(index)
         assert torch.equal(pa.cpu(), torch.gather(a, 1, ia)) and torch.equal(pb.cpu(), torch.gather(b, 1, ia))
+
+
+def test_batched_mlp_eval_golden_and_oracle(golden):
+    """All sampled nets scored in one pass (fc1 of every net as one fp32 MFMA GEMM + fused head kernel)."""
+    from oracle import evaluate as oe
+    g = golden("g10_mlp_eval")
+    nets, imgs, labels = (torch.from_numpy(g[k]) for k in ("nets", "imgs", "labels"))
+    loss, err = gpt_amd.mlp_test_losses(nets.to(DEV), imgs.to(DEV), labels.to(DEV))
+    np.testing.assert_allclose(loss.cpu().numpy(), g["loss"], rtol=2e-5)
+    np.testing.assert_allclose(err.cpu().numpy(), g["err"], rtol=0, atol=1e-4)
+    # ragged sizes (image count not a multiple of 8) and a larger batch of nets against the oracle
+    gen = torch.Generator().manual_seed(77)
+    nets = torch.randn(37, 7960, generator=gen) * 0.1
+    imgs = torch.randn(203, 1, 28, 28, generator=gen)
+    labels = torch.randint(0, 10, (203,), generator=gen)
+    want_loss, want_err = oe.mlp_eval(nets, imgs, labels)
+    loss, err = gpt_amd.mlp_test_losses(nets.to(DEV), imgs.to(DEV), labels.to(DEV))
+    np.testing.assert_allclose(loss.cpu().numpy(), want_loss.numpy(), rtol=2e-5)
+    np.testing.assert_allclose(err.cpu().numpy(), want_err.numpy(), rtol=0, atol=1e-4)
+    with pytest.raises(L.GptHipError):
+        gpt_amd.mlp_test_losses(nets, imgs, labels)                 # CPU tensors: no fallback
+
+
+def test_synth_matches_p_sample_loop_with_static_thresholding(golden):
+    """synth (Gpt/vis.py:210-252) = p_sample_loop with the harness' model_kwargs and the 'static' denoised_fn."""
+    m, plan, sd = build("mnist_small", "fp32")
+    diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000,
+                                    timestep_respacing="10")
+    _, _, lt, lp, xp = (v.to(DEV) for v in make_inputs("mnist_small", B=4, seed=9))
+    noise = torch.randn(4, m.D, generator=torch.Generator().manual_seed(3)).to(DEV)
+    with torch.no_grad():
+        a = gpt_amd.synth(diff, m, lt, lp, xp, param_range=(-0.5, 0.5), thresholding="static", noise=noise, seed=11)
+        b = diff.p_sample_loop(m, xp.shape, noise=noise, clip_denoised=False, denoised_fn=gpt_amd.StaticThreshold(-0.5, 0.5),
+                               model_kwargs=dict(loss_target=lt, loss_prev=lp, x_prev=xp), device=DEV, seed=11)
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    with pytest.raises(NotImplementedError):
+        gpt_amd.create_thresholding_fn("dynamic", (-1, 1))
+
+
+@pytest.mark.parametrize("dtype,K,tol", [("fp32", 48, 1e-5), ("bf16", 96, 2e-2)])
+def test_gemm_many_tiles_k_not_multiple_of_the_big_k_tile(dtype, K, tol):
+    """>= 128 output tiles but K is not a multiple of the 256 x 256 kernel's 128-byte K-tile: must take the ring
+    kernels (a silent K truncation would drop the last 64 bytes of every row)."""
+    code, td = L.dtype_code(dtype), L.torch_dtype(L.dtype_code(dtype))
+    g = torch.Generator().manual_seed(K)
+    M, N = 2560, 3328
+    A = torch.randn(M, K, generator=g).to(td).to(DEV)
+    W = torch.randn(N, K, generator=g).to(td).to(DEV)
+    Cm = torch.empty(M, N, device=DEV, dtype=torch.float32)
+    L.check(L.lib().gpt_gemm_nt(code, L.ptr(A), K, L.ptr(W), K, None, L.ptr(Cm), N, None, 0, M, N, K, L.EPI_STORE_F32, L.stream()),
+            "gpt_gemm_nt")
+    ref = A.double() @ W.double().t()
+    assert float((Cm.double() - ref).abs().max()) < tol * float(ref.abs().max())

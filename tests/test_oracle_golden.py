@@ -123,3 +123,12 @@ def test_g8_permute(golden):
         assert np.array_equal(op.mlp_index(*op.draw_mlp(seed)), g["mlp"][seed].astype(np.int64))
         assert np.array_equal(op.cnn_index(*op.draw_cnn(seed)), g["cnn"][seed].astype(np.int64))
         assert sorted(op.mlp_index(*op.draw_mlp(seed)).tolist()) == list(range(7960))
+
+
+def test_g10_mlp_eval(golden):
+    """The oracle's per-net functional evaluation against the reference's MLP + moduleify + cross_entropy."""
+    from oracle import evaluate as oe
+    g = golden("g10_mlp_eval")
+    loss, err = oe.mlp_eval(torch.from_numpy(g["nets"]), torch.from_numpy(g["imgs"]), torch.from_numpy(g["labels"]))
+    np.testing.assert_allclose(loss.numpy(), g["loss"], rtol=1e-5)
+    np.testing.assert_allclose(err.numpy(), g["err"], rtol=0, atol=1e-4)
