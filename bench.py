@@ -201,6 +201,17 @@ def guarded_train(args, device, world, rank, line, limit_s=150.0):
         timer.cancel()
 
 
+def pmc_traffic(case, B, dtype):
+    """Bytes per GEMM launch behind L2 from the PMC passes committed under profiles/ (FETCH_SIZE x 2 on gfx950 +
+    WRITE_SIZE, collected with rocprofv3 --pmc on this same command): counters cannot be read from inside the run, so
+    the figure is only reported for the workload it was collected on, else null."""
+    path = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+    if (case, B, dtype) != ("mnist", 320, "bf16") or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)["traffic_bytes_per_launch"]
+
+
 def sync_all(world):
     if world > 1:
         dist.barrier()
@@ -252,7 +263,7 @@ def bench_sample(args, device, world, rank):
         L.check(lib.gpt_gemm_prof_enable(0), "prof")
         achieved = fl.value / (ms.value * 1e-3) / 1e12
         line["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK[args.dtype], "unit": "TFLOP/s",
-                            "frac": achieved / PEAK[args.dtype], "traffic": None,
+                            "frac": achieved / PEAK[args.dtype], "traffic": pmc_traffic(case, B, args.dtype),
                             "kernel": "gemm_nt_kernel (qkv/proj/fc1/fc2 contractions)", "launches": nl.value,
                             "avg_launch_us": ms.value * 1e3 / max(nl.value, 1),
                             "flops_per_launch": fl.value / max(nl.value, 1)}

@@ -208,7 +208,7 @@ int split_rows(const GemmArgs<T>& g) {
   }();
   const int tn = (g.N + 255) / 256, tm = (g.M + 255) / 256, tiles = tm * tn;
   const int rounds = tiles / n_cu, rem = tiles % n_cu;
-  if (!enabled || rounds == 0 || rem == 0 || rem * 10 > n_cu * 6) return g.M;
+  if (!enabled || rounds == 0 || rem == 0 || rem * 4 > n_cu) return g.M;
   const int main_tiles_m = rounds * n_cu / tn;
   const int m_main = main_tiles_m * 256;
   if (m_main <= 0 || m_main >= g.M) return g.M;
