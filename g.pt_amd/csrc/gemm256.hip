@@ -20,6 +20,25 @@
 // instead of 0.5.  One workgroup per CU (128 KiB LDS).
 #include "gemm_common.h"
 
+#ifdef GPT_STAMPS
+// diagnostic build only: per-workgroup s_memtime stamps (no output value depends on them)
+__device__ unsigned long long g_stamps[2048 * 8];
+#define STAMP(i)                                                                        \
+  do {                                                                                  \
+    if (threadIdx.x == 0) g_stamps[(blockIdx.x & 2047) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define STAMP_RT(i)                                                                     \
+  do {                                                                                  \
+    if (threadIdx.x == 0) g_stamps[(blockIdx.x & 2047) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+extern "C" int gpt_debug_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
+}
+#else
+#define STAMP(i)
+#define STAMP_RT(i)
+#endif
+
 namespace gemmk {
 namespace {
 
@@ -44,6 +63,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g, int iter
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
 
+  STAMP_RT(4);
+  STAMP(0);
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -178,6 +199,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g, int iter
   // the first two half-tiles (h0 of both operands of K-tile 0) have landed: all but the 6 (one K-tile: 2) half-tiles issued after them
   if (nk >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  STAMP(1);
   if (wr == 1) __builtin_amdgcn_s_barrier();           // group 1 runs one barrier behind group 0
 
   for (int kt = 0; kt < nk; ++kt) {
@@ -225,6 +247,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g, int iter
 #undef SEG_READS_DONE
 #undef SEG_COMPUTE
   __syncthreads();
+  STAMP(2);
 
   if constexpr (SK) {
     // partial sums straight from the accumulator layout: a wave instruction adds to two full 128-byte lines
@@ -248,6 +271,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g, int iter
     // epilogue through a private LDS patch per wave, 32 x 32 at a time (see gemm_common.h)
     float* patch = reinterpret_cast<float*>(smem + wid * PATCH_BYTES);
     epilogue_wave<T, EPI, 4>(g, acc, patch, m0 + wr * 128, n0 + wc * 64, lane);
+#ifdef GPT_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    STAMP(3);
+    STAMP_RT(5);
+#endif
     break;
   }
   }

@@ -40,49 +40,32 @@ __device__ __forceinline__ float4 load4(const T* p) {
   }
 }
 // fp32 mode: libm erff (parity).  bf16 mode: Abramowitz-Stegun 7.1.26 (|erf error| < 1.5e-7, far below bf16's
-// 2^-9 output rounding) = one v_exp + one v_rcp + ~12 VALU instead of erff's ~40.
-__device__ __forceinline__ float gelu_fast(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+// 2^-9 output rounding) with the raw v_rcp_f32 / v_exp_f32 (1 ulp each): ~16 VALU per element instead of erff's ~40.
+// (__frcp_rn expands to the full IEEE division sequence, ~10 instructions: it made the GELU epilogue 40 k cycles.)
+__device__ __forceinline__ float erf_fast(float x) {
+  // z' = |x| sqrt(log2 e) / sqrt 2, so that exp(-z^2) = exp2(-z'^2); 0.3275911 z = P1 z'
+  constexpr float C = 0.84932180028801904272f, P1 = 0.3275911f / 1.20112240878645f;
+  const float zp = fabsf(x) * C;
+  const float t = __builtin_amdgcn_rcpf(fmaf(P1, zp, 1.0f));
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float erf_abs = 1.0f - poly * __expf(-z * z);
-  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+  const float erf_abs = fmaf(-poly, __builtin_amdgcn_exp2f(-zp * zp), 1.0f);
+  return copysignf(erf_abs, x);
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float hx = 0.5f * x;
+  return fmaf(hx, erf_fast(x), hx);
+}
+// d/dx gelu(x) = Phi(x) + x phi(x), same approximation (bf16 training mode)
+__device__ __forceinline__ float gelu_fast_grad(float x) {
+  const float cdf = fmaf(0.5f, erf_fast(x), 0.5f);
+  const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
+  return fmaf(x, pdf, cdf);
 }
 template <typename T>
 __device__ __forceinline__ float4 gelu4(const float4& v) {
   if constexpr (sizeof(T) == 4) return make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
   else return make_float4(gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w));
 }
-
-// one 4-wide row segment of the epilogue (v already holds acc + bias)
-template <typename T, int EPI>
-__device__ __forceinline__ void epi_apply(const GemmArgs<T>& g, int m, int n, const float4& v) {
-  const int64_t ci = (int64_t)m * g.ldc + n;
-  const int64_t ai = (int64_t)m * g.ldaux + n;
-  if constexpr (EPI == GPT_EPI_STORE) {
-    store4<T>((T*)g.C + ci, v);
-  } else if constexpr (EPI == GPT_EPI_GELU) {
-    store4<T>((T*)g.C + ci, gelu4<T>(v));
-  } else if constexpr (EPI == GPT_EPI_RESADD) {
-    const float4 r = g.aux ? *reinterpret_cast<const float4*>((const float*)g.aux + ai)
-                           : *reinterpret_cast<const float4*>((const float*)g.C + ci);
-    *reinterpret_cast<float4*>((float*)g.C + ci) = make_float4(r.x + v.x, r.y + v.y, r.z + v.z, r.w + v.w);
-  } else if constexpr (EPI == GPT_EPI_STORE_F32) {
-    *reinterpret_cast<float4*>((float*)g.C + ci) = v;
-  } else if constexpr (EPI == GPT_EPI_GELU_AUX) {
-    store4<T>((T*)g.aux + ai, v);
-    store4<T>((T*)g.C + ci, gelu4<T>(v));
-  } else if constexpr (EPI == GPT_EPI_DGELU) {
-    const float4 pre = load4<T>((const T*)g.aux + ai);
-    store4<T>((T*)g.C + ci, make_float4(v.x * gelu_erf_grad(pre.x), v.y * gelu_erf_grad(pre.y),
-                                         v.z * gelu_erf_grad(pre.z), v.w * gelu_erf_grad(pre.w)));
-  } else if constexpr (EPI == GPT_EPI_ACCUM_F32) {
-    float4* c = reinterpret_cast<float4*>((float*)g.C + ci);
-    const float4 r = *c;
-    *c = make_float4(r.x + v.x, r.y + v.y, r.z + v.z, r.w + v.w);
-  }
-}
-
 
 // ---------------------------------------------------------------------------------------------------------
 // Wave-level epilogue shared by the kernels.  A wave owns NI x 2 MFMA 32x32 accumulator tiles = (32 NI) x 64
@@ -91,6 +74,14 @@ __device__ __forceinline__ void epi_apply(const GemmArgs<T>& g, int m, int n, co
 // bf16 outputs leave as ONE 16-byte store per lane and every row of the wave's 64 columns is written as a
 // full 128-byte line (fp32: 256 bytes = two lines).  Only the wave itself touches its patch: no workgroup
 // barrier.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+// Ordering of the wave's own patch writes and reads: the LDS executes one wave's DS instructions in issue order, so only
+// the COMPILER must be kept from moving them across this point.  (A wavefront-scope fence is lowered by hipcc to
+// s_waitcnt vmcnt(0): it drained the global stores 16 times per tile and made the epilogue 19 k cycles long.)
+#define WAVE_LDS_ORDER()                                   \
+  do {                                                     \
+    asm volatile("" ::: "memory");                         \
+    __builtin_amdgcn_wave_barrier();                       \
+  } while (0)
 constexpr int PATCH_PITCH = 68;
 constexpr int PATCH_BYTES = 32 * PATCH_PITCH * 4;
 
@@ -118,36 +109,56 @@ __device__ __forceinline__ void load8(const T* p, float4& a, float4& b) {
   }
 }
 __device__ __forceinline__ float4 add4(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+template <typename T>
 __device__ __forceinline__ float4 dgelu4(const float4& v, const float4& pre) {
-  return make_float4(v.x * gelu_erf_grad(pre.x), v.y * gelu_erf_grad(pre.y), v.z * gelu_erf_grad(pre.z), v.w * gelu_erf_grad(pre.w));
+  if constexpr (sizeof(T) == 4)
+    return make_float4(v.x * gelu_erf_grad(pre.x), v.y * gelu_erf_grad(pre.y), v.z * gelu_erf_grad(pre.z), v.w * gelu_erf_grad(pre.w));
+  else
+    return make_float4(v.x * gelu_fast_grad(pre.x), v.y * gelu_fast_grad(pre.y), v.z * gelu_fast_grad(pre.z), v.w * gelu_fast_grad(pre.w));
 }
 
-// 8 consecutive columns of row m starting at column n (n % 8 == 0; the caller checked m < M, n < N; N % 8 == 0)
+// What an epilogue READS for 8 consecutive columns of one row (the residual, the running sum or the pre-activation).
+// Loaded one 32-row step ahead of its use so that no wait on it ever covers the stores issued after it.
+template <int EPI>
+constexpr bool epi_reads = EPI == GPT_EPI_RESADD || EPI == GPT_EPI_ACCUM_F32 || EPI == GPT_EPI_DGELU;
+struct EpiPre {
+  float4 a, b;
+};
 template <typename T, int EPI>
-__device__ __forceinline__ void epi_apply8(const GemmArgs<T>& g, int m, int n, const float4& a, const float4& b) {
+__device__ __forceinline__ void epi_load8(const GemmArgs<T>& g, int m, int n, EpiPre& p) {
+  const int64_t ci = (int64_t)m * g.ldc + n;
+  const int64_t ai = (int64_t)m * g.ldaux + n;
+  if constexpr (EPI == GPT_EPI_RESADD) {
+    const float* rp = g.aux ? (const float*)g.aux + ai : (const float*)g.C + ci;
+    p.a = reinterpret_cast<const float4*>(rp)[0];
+    p.b = reinterpret_cast<const float4*>(rp)[1];
+  } else if constexpr (EPI == GPT_EPI_ACCUM_F32) {
+    const float* c = (const float*)g.C + ci;
+    p.a = reinterpret_cast<const float4*>(c)[0];
+    p.b = reinterpret_cast<const float4*>(c)[1];
+  } else if constexpr (EPI == GPT_EPI_DGELU) {
+    load8<T>((const T*)g.aux + ai, p.a, p.b);
+  }
+}
+
+// 8 consecutive columns of row m starting at column n (n % 8 == 0; m < M, n < N; N % 8 == 0); a | b = acc + bias
+template <typename T, int EPI>
+__device__ __forceinline__ void epi_store8(const GemmArgs<T>& g, int m, int n, const float4& a, const float4& b, const EpiPre& p) {
   const int64_t ci = (int64_t)m * g.ldc + n;
   const int64_t ai = (int64_t)m * g.ldaux + n;
   if constexpr (EPI == GPT_EPI_STORE) {
     store8<T>((T*)g.C + ci, a, b);
   } else if constexpr (EPI == GPT_EPI_GELU) {
     store8<T>((T*)g.C + ci, gelu4<T>(a), gelu4<T>(b));
-  } else if constexpr (EPI == GPT_EPI_RESADD) {
-    const float* rp = g.aux ? (const float*)g.aux + ai : (const float*)g.C + ci;
-    const float4 r0 = reinterpret_cast<const float4*>(rp)[0], r1 = reinterpret_cast<const float4*>(rp)[1];
-    store8<float>((float*)g.C + ci, add4(r0, a), add4(r1, b));
+  } else if constexpr (EPI == GPT_EPI_RESADD || EPI == GPT_EPI_ACCUM_F32) {
+    store8<float>((float*)g.C + ci, add4(p.a, a), add4(p.b, b));
   } else if constexpr (EPI == GPT_EPI_STORE_F32) {
     store8<float>((float*)g.C + ci, a, b);
   } else if constexpr (EPI == GPT_EPI_GELU_AUX) {
     store8<T>((T*)g.aux + ai, a, b);
     store8<T>((T*)g.C + ci, gelu4<T>(a), gelu4<T>(b));
   } else if constexpr (EPI == GPT_EPI_DGELU) {
-    float4 p0, p1;
-    load8<T>((const T*)g.aux + ai, p0, p1);
-    store8<T>((T*)g.C + ci, dgelu4(a, p0), dgelu4(b, p1));
-  } else if constexpr (EPI == GPT_EPI_ACCUM_F32) {
-    float* c = (float*)g.C + ci;
-    const float4 r0 = reinterpret_cast<const float4*>(c)[0], r1 = reinterpret_cast<const float4*>(c)[1];
-    store8<float>(c, add4(r0, a), add4(r1, b));
+    store8<T>((T*)g.C + ci, dgelu4<T>(a, p.a), dgelu4<T>(b, p.b));
   }
 }
 
@@ -162,26 +173,62 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs<T>& g, const f32x16
     b0 = reinterpret_cast<const float4*>(g.bias + n)[0];
     b1 = reinterpret_cast<const float4*>(g.bias + n)[1];
   }
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
+  // the bias is consumed HERE as far as the compiler can tell: otherwise its first use sits inside the steps below and
+  // hipcc's wait for it (s_waitcnt vmcnt(0), repeated after every branch) drains the stores of every step
+  asm volatile("" : "+v"(b0.x), "+v"(b0.y), "+v"(b0.z), "+v"(b0.w), "+v"(b1.x), "+v"(b1.y), "+v"(b1.z), "+v"(b1.w));
+  auto to_patch = [&](int i) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + 4 * fh) * PATCH_PITCH + j * 32 + fr] = acc[i][j][e];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  // wave-uniform: the wave's whole (32 NI) x 64 block lies inside the matrix -> straight-line code, counted waits
+  const bool full = __builtin_amdgcn_readfirstlane((mrow0 + 32 * NI <= g.M && ncol0 + 64 <= g.N) ? 1 : 0) != 0;
+  if (full) {
+    EpiPre pre[2][4];
+    if constexpr (epi_reads<EPI>) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) epi_load8<T, EPI>(g, mrow0 + p * 8 + pr, n, pre[0][p]);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      to_patch(i);
+      WAVE_LDS_ORDER();
+      if constexpr (epi_reads<EPI>) {
+        if (i + 1 < NI) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) epi_load8<T, EPI>(g, mrow0 + (i + 1) * 32 + p * 8 + pr, n, pre[(i + 1) & 1][p]);
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int row = p * 8 + pr;
+        const float4 v0 = *reinterpret_cast<const float4*>(patch + row * PATCH_PITCH + pc8);
+        const float4 v1 = *reinterpret_cast<const float4*>(patch + row * PATCH_PITCH + pc8 + 4);
+        epi_store8<T, EPI>(g, mrow0 + i * 32 + row, n, add4(v0, b0), add4(v1, b1), pre[i & 1][p]);
+      }
+      WAVE_LDS_ORDER();
+    }
+    return;
+  }
+  // edge tiles: per-lane bounds
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    to_patch(i);
+    WAVE_LDS_ORDER();
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int row = p * 8 + pr;
       const int m = mrow0 + i * 32 + row;
       const float4 v0 = *reinterpret_cast<const float4*>(patch + row * PATCH_PITCH + pc8);
       const float4 v1 = *reinterpret_cast<const float4*>(patch + row * PATCH_PITCH + pc8 + 4);
-      if (m < g.M && n < g.N) epi_apply8<T, EPI>(g, m, n, add4(v0, b0), add4(v1, b1));
+      if (m < g.M && n < g.N) {
+        EpiPre pre;
+        if constexpr (epi_reads<EPI>) epi_load8<T, EPI>(g, m, n, pre);
+        epi_store8<T, EPI>(g, m, n, add4(v0, b0), add4(v1, b1), pre);
+      }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    WAVE_LDS_ORDER();
   }
 }
 
