@@ -30,7 +30,6 @@
 namespace gemmk {
 GemmProf g_prof;
 int gemm256_bf16(const GemmArgs<bf16_t>& g, int epi, hipStream_t s);  // gemm256.hip
-bool gemm256_stream_k(const GemmArgs<bf16_t>& g, int epi);            // gemm256.hip: would run as stream-K
 int gemm256_f32(const GemmArgs<float>& g, int epi, hipStream_t s);
 }
 
@@ -141,7 +140,13 @@ __global__ __launch_bounds__(WM * 128, WM) void gemm_nt_kernel(GemmArgs<T> g) {
 
   // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   float* patch = reinterpret_cast<float*>(smem + wid * PATCH_BYTES);
-  epilogue_wave<T, EPI, 2>(g, acc, patch, m0 + wr * 64, n0 + wc * 64, lane);
+  auto to_patch = [&](int step) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + 4 * fh) * PATCH_PITCH + j * 32 + fr] = acc[step][j][e];
+  };
+  epilogue_wave<T, EPI, 2>(g, to_patch, patch, m0 + wr * 64, n0 + wc * 64, lane);
 }
 
 
@@ -220,11 +225,9 @@ int split_rows(const GemmArgs<T>& g) {
 template <typename T>
 int dispatch(const GemmArgs<T>& g, int epi, hipStream_t s) {
   const int tiles256 = ((g.M + 255) / 256) * ((g.N + 255) / 256);
-  bool sk = false;
-  if constexpr (sizeof(T) == 2) sk = tile_mode() == 0 && tiles256 >= 16 && gemm256_stream_k(g, epi);
   const bool k_ok = g.K % (128 / (int)sizeof(T)) == 0;   // the 256 x 256 kernel moves 128 bytes of K per row and K-tile
-  if (k_ok && (tile_mode() == 3 || (tile_mode() == 0 && tiles256 >= 128) || sk)) {
-    const int m_main = tile_mode() == 0 && !sk ? split_rows(g) : g.M;
+  if (k_ok && (tile_mode() == 3 || (tile_mode() == 0 && tiles256 >= 128))) {
+    const int m_main = tile_mode() == 0 ? split_rows(g) : g.M;
     GemmArgs<T> head = g;
     head.M = m_main;
     int rc;

@@ -52,12 +52,10 @@ __device__ __forceinline__ u32x4 frag(const char* half, int row, int lc) {
   return *reinterpret_cast<const u32x4*>(half + row * RB + ((lc ^ ((row >> 1) & 7)) << 4));
 }
 
-// SK (stream-K): the launch has one workgroup per CU and the tile x K-tile iteration space is cut into equal
-// contiguous spans, one per workgroup, so no CU idles in a last, partly filled round.  A span covers pieces of
-// (at most a few) tiles; each piece's partial sum is ADDED to the fp32 output with hardware float atomics, which is
-// why only the additive epilogues (RESADD in place, ACCUM_F32) can run this way.  `iters_per_wg` > 0 selects it.
-template <typename T, int EPI, bool SK>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g, int iters_per_wg) {
+// (A stream-K variant - one workgroup per CU, equal spans of the tile x K-tile space, partial tiles added with float
+// atomics - was built and measured in r01: slower on every shape of this model, proj 70 -> 154 us; removed.)
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -75,13 +73,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g, int iter
   const int nk_tile = g.K / BK;
   const int fr = lane & 31, fh = lane >> 5;
 
-  int it = SK ? swz * iters_per_wg : 0;
-  const int it_end = SK ? min(it + iters_per_wg, tiles_n * ((g.M + 255) / 256) * nk_tile) : 0;
-  if (SK && it >= it_end) return;
-  for (;;) {
-  const int tile = SK ? it / nk_tile : swz;
-  const int kb = SK ? it - tile * nk_tile : 0;
-  const int nk = SK ? min(nk_tile - kb, it_end - it) : nk_tile;
+  const int tile = swz, nk = nk_tile;
   // tile order inside an XCD's contiguous run: column groups of GROUP_N tiles, rows fastest across the group, so
   // the ~32 tiles an XCD works on at once form a ~4 x 8 block (A and W panels both re-used from its 4 MiB L2)
 #ifndef GPT_GROUP_N
@@ -104,10 +96,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g, int iter
     for (int h = 0; h < 2; ++h) {
       int gm = m0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
       gm = gm < g.M ? gm : g.M - 1;
-      srcA[h][p] = g.A + (int64_t)gm * g.lda + lc * EPC + (int64_t)kb * BK;
+      srcA[h][p] = g.A + (int64_t)gm * g.lda + lc * EPC;
       int gn = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
       gn = gn < g.N ? gn : g.N - 1;
-      srcW[h][p] = g.W + (int64_t)gn * g.ldw + lc * EPC + (int64_t)kb * BK;
+      srcW[h][p] = g.W + (int64_t)gn * g.ldw + lc * EPC;
     }
   }
   auto dma = [&](const T* const (&src)[2], int kt, int slot) {
@@ -116,13 +108,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g, int iter
     __builtin_amdgcn_global_load_lds((gptr_t)(src[1] + kt * BK), (lptr_t)(dst + 1024), 16, 0, 0);
   };
 
-  f32x16 acc[4][2];
+  // bf16: 16x16x32 MFMAs, 8 x 4 accumulator tiles of 16 x 16 (the chip holds a higher clock on this shape than on
+  // 32x32x16 at the same cycles per FLOP and the same LDS traffic: +4...8 % measured);  fp32: 32x32x2, 4 x 2 tiles of 32 x 32
+  constexpr bool M16 = sizeof(T) == 2;
+  f32x4 acc16[M16 ? 8 : 1][M16 ? 4 : 1];
+  f32x16 acc[M16 ? 1 : 4][M16 ? 1 : 2];
+  if constexpr (M16) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  } else {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  }
 
   // prologue: K-tiles 0 and 1 in consumption order
 #pragma unroll
@@ -134,42 +137,55 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g, int iter
       dma(srcA[1], t, 1);
     }
 
+  // one quadrant of the wave tile x one K-tile.  Fragment arrays: fp32 / 32x32: a[i][ks] = rows 32 i.., k-step ks of 4;
+  // bf16 / 16x16: the same 8 + 4 registers viewed as a[i][kk] -> a[i >> 1][2 * (i & 1) + kk], i < 4 row tiles, kk < 2
   auto mma = [&](const u32x4 (&a)[2][4], const u32x4 (&b)[4], int i0, int j) {
-#ifdef GPT_FAKE16
-    // timing experiment only (wrong numerics): the same FLOPs and operand traffic issued as 16x16x32 MFMAs
-    if constexpr (sizeof(T) == 2) {
-      typedef __attribute__((ext_vector_type(8))) float f32x8;
+    if constexpr (M16) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ks += 2)
+      for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          f32x16 c = acc[i0 + i][j];
-          f32x4 q0 = __builtin_shufflevector(c, c, 0, 1, 2, 3), q1 = __builtin_shufflevector(c, c, 4, 5, 6, 7);
-          f32x4 q2 = __builtin_shufflevector(c, c, 8, 9, 10, 11), q3 = __builtin_shufflevector(c, c, 12, 13, 14, 15);
-          q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i][ks]), __builtin_bit_cast(bf16x8, b[ks]), q0, 0, 0, 0);
-          q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i][ks + 1]), __builtin_bit_cast(bf16x8, b[ks]), q1, 0, 0, 0);
-          q2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i][ks]), __builtin_bit_cast(bf16x8, b[ks + 1]), q2, 0, 0, 0);
-          q3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i][ks + 1]), __builtin_bit_cast(bf16x8, b[ks + 1]), q3, 0, 0, 0);
-          f32x8 lo = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7), hi = __builtin_shufflevector(q2, q3, 0, 1, 2, 3, 4, 5, 6, 7);
-          acc[i0 + i][j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-        }
-      return;
-    }
-#endif
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+          for (int jj = 0; jj < 2; ++jj)
+            acc16[4 * (i0 >> 1) + i][2 * j + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, a[i >> 1][2 * (i & 1) + kk]), __builtin_bit_cast(bf16x8, b[2 * jj + kk]),
+                acc16[4 * (i0 >> 1) + i][2 * j + jj], 0, 0, 0);
+    } else {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if constexpr (sizeof(T) == 2) {
-          acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i][ks]),
-                                                                  __builtin_bit_cast(bf16x8, b[ks]), acc[i0 + i][j], 0, 0, 0);
-        } else {
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[i][ks][e]), __uint_as_float(b[ks][e]),
                                                                   acc[i0 + i][j], 0, 0, 0);
-        }
-      }
+    }
+  };
+  // fragment reads of one half-tile: A half = 64 rows of this wave (base row wr * 64), W half = 32 columns (base wc * 32)
+  const int l15 = lane & 15, l4 = lane >> 4;
+  auto read_a = [&](u32x4 (&a)[2][4], const char* half) {
+    if constexpr (M16) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) a[i >> 1][2 * (i & 1) + kk] = frag(half, wr * 64 + i * 16 + l15, 4 * kk + l4);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) a[i][ks] = frag(half, wr * 64 + i * 32 + fr, 2 * ks + fh);
+    }
+  };
+  auto read_b = [&](u32x4 (&b)[4], const char* half) {
+    if constexpr (M16) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) b[2 * jj + kk] = frag(half, wc * 32 + jj * 16 + l15, 4 * kk + l4);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) b[ks] = frag(half, wc * 32 + fr, 2 * ks + fh);
+    }
   };
   // Two wave groups (wr = 0 / 1: one wave of each on every SIMD) run ONE BARRIER APART: every phase is
   // {load segment: wait, barrier, ds_reads, DMA issue} barrier {compute segment: 8 MFMAs}, so while one group
@@ -209,29 +225,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g, int iter
     // ---- p0: A-h0 x W-h0        (retire W-h1(kt) for p1)
     SEG_WAIT();
     SEG_BARRIER();
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) b0[ks] = frag(buf + 2 * HALF, wc * 32 + fr, 2 * ks + fh);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) a[i][ks] = frag(buf, wr * 64 + i * 32 + fr, 2 * ks + fh);
+    read_b(b0, buf + 2 * HALF);
+    read_a(a, buf);
     if (kt >= 1 && kt + 1 < nk) dma(srcA[1], kt + 1, 1);   // A-h1(kt+1): its slot was last read in p2(kt-1)
     SEG_READS_DONE();
     SEG_COMPUTE(a, b0, 0, 0);
     // ---- p1: A-h0 x W-h1        (retire A-h1(kt) for p2)
     SEG_WAIT();
     SEG_BARRIER();
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) b1[ks] = frag(buf + 3 * HALF, wc * 32 + fr, 2 * ks + fh);
+    read_b(b1, buf + 3 * HALF);
     if (steady) dma(srcA[0], kt + 2, 0);                    // A-h0 slot of this buffer: read in p0
     SEG_READS_DONE();
     SEG_COMPUTE(a, b1, 0, 1);
     // ---- p2: A-h1 x W-h1
     SEG_BARRIER();
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) a[i][ks] = frag(buf + HALF, wr * 64 + i * 32 + fr, 2 * ks + fh);
+    read_a(a, buf + HALF);
     if (steady) dma(srcW[0], kt + 2, 2);                    // W-h0 slot: read in p0 (kept in registers)
     SEG_READS_DONE();
     SEG_COMPUTE(a, b1, 2, 1);
@@ -249,53 +257,39 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g, int iter
   __syncthreads();
   STAMP(2);
 
-  if constexpr (SK) {
-    // partial sums straight from the accumulator layout: a wave instruction adds to two full 128-byte lines
-    // (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)); the piece that starts the tile adds the bias
+  // epilogue through a private LDS patch per wave, 32 rows x 64 columns at a time (see gemm_common.h)
+  float* patch = reinterpret_cast<float*>(smem + wid * PATCH_BYTES);
+  auto to_patch = [&](int step) {
+    if constexpr (M16) {
+      // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wc * 64 + j * 32 + fr;
-      if (n >= g.N) continue;
-      const float bias = (kb == 0 && g.bias) ? g.bias[n] : 0.f;
+      for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = m0 + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-          if (m < g.M) unsafeAtomicAdd((float*)g.C + (int64_t)m * g.ldc + n, acc[i][j][e] + bias);
-        }
+          for (int e = 0; e < 4; ++e) patch[(ii * 16 + 4 * l4 + e) * PATCH_PITCH + jt * 16 + l15] = acc16[2 * step + ii][jt][e];
+    } else {
+      // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + 4 * fh) * PATCH_PITCH + j * 32 + fr] = acc[step][j][e];
     }
-    it += nk;
-    if (it >= it_end) break;
-  } else {
-    // epilogue through a private LDS patch per wave, 32 x 32 at a time (see gemm_common.h)
-    float* patch = reinterpret_cast<float*>(smem + wid * PATCH_BYTES);
-    epilogue_wave<T, EPI, 4>(g, acc, patch, m0 + wr * 128, n0 + wc * 64, lane);
+  };
+  epilogue_wave<T, EPI, 4>(g, to_patch, patch, m0 + wr * 128, n0 + wc * 64, lane);
 #ifdef GPT_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    STAMP(3);
-    STAMP_RT(5);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  STAMP(3);
+  STAMP_RT(5);
 #endif
-    break;
-  }
-  }
 }
 
-int n_cus() {
-  static const int n = [] {
-    int dev = 0, v = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
-    return v > 0 ? v : 256;
-  }();
-  return n;
-}
-
-template <typename T, int EPI, bool SK>
+template <typename T, int EPI>
 int launch256(const GemmArgs<T>& g, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm256_kernel<T, EPI, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+    if (hipFuncSetAttribute((const void*)gemm256_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
         hipSuccess) {
       gpt_set_error("gpt_gemm_nt: cannot reserve %d bytes of LDS", LDS_BYTES);
       return -1;
@@ -303,16 +297,10 @@ int launch256(const GemmArgs<T>& g, hipStream_t s) {
     attr_set = true;
   }
   const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
-  int grid = tiles, ipw = 0;
-  if (SK) {
-    const int total = tiles * (g.K / (RB / (int)sizeof(T)));
-    grid = n_cus();
-    ipw = (total + grid - 1) / grid;
-    grid = (total + ipw - 1) / ipw;
-  }
+  const int grid = tiles;
   const bool rec = g_prof.on && g_prof.n < GemmProf::CAP;
   if (rec) (void)hipEventRecord(g_prof.ev[g_prof.n][0], s);
-  hipLaunchKernelGGL((gemm256_kernel<T, EPI, SK>), dim3(grid), dim3(512), LDS_BYTES, s, g, ipw);
+  hipLaunchKernelGGL((gemm256_kernel<T, EPI>), dim3(grid), dim3(512), LDS_BYTES, s, g);
   if (rec) {
     (void)hipEventRecord(g_prof.ev[g_prof.n][1], s);
     g_prof.flops[g_prof.n++] = 2.0 * g.M * g.N * g.K;
@@ -320,35 +308,16 @@ int launch256(const GemmArgs<T>& g, hipStream_t s) {
   return gpt_launch_status("gpt_gemm_nt");
 }
 
-// Stream-K pays when the additive epilogue allows it, the data-parallel launch would leave its last round badly
-// filled, and every workgroup still gets a few K-tiles.  bf16 only: the exact-fp32 parity mode stays order-deterministic.
-template <typename T>
-bool use_stream_k(const GemmArgs<T>& g, int epi) {
-  static const bool enabled = [] {
-    // OFF by default: measured slower on every shape of this model (r01: proj 70 -> 154 us, fc2 189 -> 251 us, the
-    // B=1024 wgrads 544 -> 626 us): ~65 k float atomics per piece cost more than the idle CUs they recover
-    const char* e = getenv("GPT_GEMM_STREAMK");
-    return e && atoi(e) != 0;
-  }();
-  if (!enabled || sizeof(T) != 2) return false;
-  if (!(epi == GPT_EPI_ACCUM_F32 || (epi == GPT_EPI_RESADD && g.aux == nullptr))) return false;
-  const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256), n = n_cus();
-  const int rounds = (tiles + n - 1) / n;
-  const int total = tiles * (g.K / (RB / (int)sizeof(T)));
-  return tiles * 100 < rounds * n * 88 && total >= 6 * n;
-}
-
 template <typename T>
 int dispatch256(const GemmArgs<T>& g, int epi, hipStream_t s) {
-  if (use_stream_k(g, epi)) return launch256<T, GPT_EPI_ACCUM_F32, true>(g, s);
   switch (epi) {
-    case GPT_EPI_STORE: return launch256<T, GPT_EPI_STORE, false>(g, s);
-    case GPT_EPI_GELU: return launch256<T, GPT_EPI_GELU, false>(g, s);
-    case GPT_EPI_RESADD: return launch256<T, GPT_EPI_RESADD, false>(g, s);
-    case GPT_EPI_STORE_F32: return launch256<T, GPT_EPI_STORE_F32, false>(g, s);
-    case GPT_EPI_GELU_AUX: return launch256<T, GPT_EPI_GELU_AUX, false>(g, s);
-    case GPT_EPI_DGELU: return launch256<T, GPT_EPI_DGELU, false>(g, s);
-    case GPT_EPI_ACCUM_F32: return launch256<T, GPT_EPI_ACCUM_F32, false>(g, s);
+    case GPT_EPI_STORE: return launch256<T, GPT_EPI_STORE>(g, s);
+    case GPT_EPI_GELU: return launch256<T, GPT_EPI_GELU>(g, s);
+    case GPT_EPI_RESADD: return launch256<T, GPT_EPI_RESADD>(g, s);
+    case GPT_EPI_STORE_F32: return launch256<T, GPT_EPI_STORE_F32>(g, s);
+    case GPT_EPI_GELU_AUX: return launch256<T, GPT_EPI_GELU_AUX>(g, s);
+    case GPT_EPI_DGELU: return launch256<T, GPT_EPI_DGELU>(g, s);
+    case GPT_EPI_ACCUM_F32: return launch256<T, GPT_EPI_ACCUM_F32>(g, s);
   }
   gpt_set_error("gpt_gemm_nt: unknown epilogue %d", epi);
   return -1;
@@ -357,7 +326,6 @@ int dispatch256(const GemmArgs<T>& g, int epi, hipStream_t s) {
 }  // namespace
 
 int gemm256_bf16(const GemmArgs<bf16_t>& g, int epi, hipStream_t s) { return dispatch256<bf16_t>(g, epi, s); }
-bool gemm256_stream_k(const GemmArgs<bf16_t>& g, int epi) { return use_stream_k<bf16_t>(g, epi); }
 int gemm256_f32(const GemmArgs<float>& g, int epi, hipStream_t s) { return dispatch256<float>(g, epi, s); }
 
 }  // namespace gemmk

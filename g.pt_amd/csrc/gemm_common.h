@@ -162,10 +162,10 @@ __device__ __forceinline__ void epi_store8(const GemmArgs<T>& g, int m, int n, c
   }
 }
 
-template <typename T, int EPI, int NI>
-__device__ __forceinline__ void epilogue_wave(const GemmArgs<T>& g, const f32x16 (&acc)[NI][2], float* patch, int mrow0,
+// to_patch(step): writes rows [32 step, 32 step + 32) x 64 columns of the wave's accumulators to patch[row][col]
+template <typename T, int EPI, int NI, typename ToPatch>
+__device__ __forceinline__ void epilogue_wave(const GemmArgs<T>& g, ToPatch&& to_patch, float* patch, int mrow0,
                                               int ncol0, int lane) {
-  const int fr = lane & 31, fh = lane >> 5;
   const int pr = lane >> 3, pc8 = (lane & 7) * 8;
   const int n = ncol0 + pc8;
   float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
@@ -176,12 +176,6 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs<T>& g, const f32x16
   // the bias is consumed HERE as far as the compiler can tell: otherwise its first use sits inside the steps below and
   // hipcc's wait for it (s_waitcnt vmcnt(0), repeated after every branch) drains the stores of every step
   asm volatile("" : "+v"(b0.x), "+v"(b0.y), "+v"(b0.z), "+v"(b0.w), "+v"(b1.x), "+v"(b1.y), "+v"(b1.z), "+v"(b1.w));
-  auto to_patch = [&](int i) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + 4 * fh) * PATCH_PITCH + j * 32 + fr] = acc[i][j][e];
-  };
   // wave-uniform: the wave's whole (32 NI) x 64 block lies inside the matrix -> straight-line code, counted waits
   const bool full = __builtin_amdgcn_readfirstlane((mrow0 + 32 * NI <= g.M && ncol0 + 64 <= g.N) ? 1 : 0) != 0;
   if (full) {
