@@ -1,19 +1,22 @@
 // 256 x 256 block-tile MFMA GEMM for gfx950 (the large-problem path of gpt_gemm_nt).
 //
-// 8 waves (2 x 4), each owning 128 x 64 of the output = 4 x 2 MFMA 32x32 tiles (128 accumulator registers).
-// K-tile = 128 bytes of K per row (64 bf16 / 32 fp32).  LDS = 2 K-tile buffers x 64 KiB, each buffer split
-// into FOUR 16-KiB half-tiles: A-h0 / A-h1 hold the first / second 64 rows of every wave-row's 128,
-// W-h0 / W-h1 the first / second 32 columns of every wave-column's 64.  A K-tile is consumed in four phases,
-// one 64 x 32 quadrant of the wave tile each (8 MFMAs):
-//     p0: (A-h0, W-h0)   p1: (A-h0, W-h1)   p2: (A-h1, W-h1)   p3: (A-h1, W-h0, from registers)
-// so a half-tile slot is free again after ONE phase, and the LDS-DMA that refills it (for K-tile t+2, same
-// buffer) is issued in the very next phase: p1: A-h0(t+2), p2: W-h0(t+2), p3: W-h1(t+2), p0': A-h1(t+2).
-// Every DMA therefore has 6-7 phases (about 1.5 K-tiles of MFMA work) to land, with only two buffers.
-// Waits are COUNTED: before the reads of p0/p1/p2 a wave waits s_waitcnt vmcnt(10) - the five half-tiles
-// issued after the one it needs (2 DMA instructions each) may still be in flight - then a raw s_barrier
-// (a __syncthreads() would drain the DMA queue).  The last two K-tiles drain with vmcnt(0).
-// WAR safety: a slot read in phase p is refilled after the barrier that opens phase p+1, which every wave
-// reaches only after its own phase-p reads have returned (lgkmcnt(0) before its MFMAs).
+// 8 waves (2 x 4), each owning 128 x 64 of the output: bf16 as 8 x 4 MFMA 16x16x32 tiles, fp32 as 4 x 2 MFMA 32x32x2
+// tiles (128 accumulator registers either way).  K-tile = 128 bytes of K per row (64 bf16 / 32 fp32).
+// LDS = 2 K-tile buffers x 64 KiB, each buffer split into FOUR 16-KiB half-tiles: A-h0 / A-h1 hold the first /
+// second 64 rows of every wave-row's 128, W-h0 / W-h1 the first / second 32 columns of every wave-column's 64.
+// A K-tile is consumed in TWO phases of two 64 x 32 quadrants each:
+//     P0: reads A-h0, W-h0, W-h1 -> (A-h0, W-h0), (A-h0, W-h1)     P1: reads A-h1 -> (A-h1, W-h1), (A-h1, W-h0)
+// and the LDS-DMA refills of a buffer (for K-tile t+2) are issued as soon as its slots have been read:
+//     P1(t): A-h0, W-h0, W-h1 (t+2)      P0(t+1): A-h1 (t+2)
+// so every DMA has about three phases (1.5 K-tiles of MFMA work) to land, with only two buffers.
+// Waits are COUNTED (s_waitcnt vmcnt(6) / vmcnt(2): the DMA instructions issued after the half-tiles a phase
+// retires may still be in flight) and followed by a raw s_barrier (a __syncthreads() would drain the DMA queue).
+// WAR safety: a slot read in a phase is refilled after the barrier that opens the next phase, which every wave
+// reaches only after its own reads have returned (lgkmcnt(0) before its MFMAs).
+// r01 measurements that shaped it (tools/gemm_stamps.py, s_memtime stamps): four phases per K-tile cost 2970
+// cycles per K-tile against 2048 of MFMA issue, most of the gap being barrier hand-offs; two phases: 2700.  The chip
+// is power-limited in this loop (1.6 - 2.1 GHz sustained): part of every cycle saved comes back as a lower clock, and
+// the 16x16x32 MFMA shape sustains a higher clock than 32x32x16 at equal cycles and LDS traffic (+4...8 % wall).
 //
 // Operand traffic per FLOP is half that of a 128 x 128 tile (L2 -> LDS is the scarce resource here: a CU's
 // vector-memory path moves 64 B/clk), LDS reads per MFMA 0.75 instead of 1, DMA instructions per MFMA 0.25
@@ -188,15 +191,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
     }
   };
   // Two wave groups (wr = 0 / 1: one wave of each on every SIMD) run ONE BARRIER APART: every phase is
-  // {load segment: wait, barrier, ds_reads, DMA issue} barrier {compute segment: 8 MFMAs}, so while one group
+  // {load segment: wait, barrier, ds_reads, DMA issue} barrier {compute segment: 32 MFMAs}, so while one group
   // multiplies, its SIMD partner reads LDS and issues DMA; the matrix pipe alternates between the two.
   // Because of the offset a wave retires (vmcnt) the DMA of a half-tile ONE PHASE BEFORE the phase that reads
   // it: the other group's pieces are then covered by a barrier that group has passed as well.
-#define SEG_WAIT()                                                          \
-  do {                                                                      \
-    if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   \
-  } while (0)
 #define SEG_BARRIER()                        \
   do {                                       \
     __builtin_amdgcn_sched_barrier(0);       \
@@ -204,56 +202,56 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
     __builtin_amdgcn_sched_barrier(0);       \
   } while (0)
 #define SEG_READS_DONE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#define SEG_COMPUTE(A_, B_, I0, J)           \
-  do {                                       \
-    SEG_BARRIER();                           \
-    __builtin_amdgcn_s_setprio(1);           \
-    mma(A_, B_, I0, J);                      \
-    __builtin_amdgcn_s_setprio(0);           \
-  } while (0)
 
-  // the first two half-tiles (h0 of both operands of K-tile 0) have landed: all but the 6 (one K-tile: 2) half-tiles issued after them
-  if (nk >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  // TWO phases per K-tile (32 MFMAs each) instead of four: half the barriers, whose hand-off latency (~100 cycles of
+  // idle matrix pipe per interval) was the largest loss of the 4-phase loop (2970 cycles per K-tile against 2048 of MFMA).
+  //   P0: reads A-h0, W-h0, W-h1 (16 ds_read_b128)  -> (A-h0 x W-h0), (A-h0 x W-h1);   refills A-h1(kt+1)
+  //   P1: reads A-h1 (8)                            -> (A-h1 x W-h1), (A-h1 x W-h0);   refills A-h0, W-h0, W-h1 (kt+2)
+  // Retire-one-phase-ahead waits: P0 retires A-h1(kt) (6 younger DMA instructions), P1 retires the three half-tiles of
+  // kt+1 (2 younger).
+  if (nk >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   STAMP(1);
   if (wr == 1) __builtin_amdgcn_s_barrier();           // group 1 runs one barrier behind group 0
 
   for (int kt = 0; kt < nk; ++kt) {
     const char* buf = smem + (kt & 1) * BUF;
-    const bool steady = kt + 2 < nk;
+    const bool steady = kt + 2 < nk, last = kt + 1 == nk;
     u32x4 a[2][4], b0[4], b1[4];
-    // ---- p0: A-h0 x W-h0        (retire W-h1(kt) for p1)
-    SEG_WAIT();
+    // ---- P0
+    if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     SEG_BARRIER();
     read_b(b0, buf + 2 * HALF);
     read_a(a, buf);
-    if (kt >= 1 && kt + 1 < nk) dma(srcA[1], kt + 1, 1);   // A-h1(kt+1): its slot was last read in p2(kt-1)
-    SEG_READS_DONE();
-    SEG_COMPUTE(a, b0, 0, 0);
-    // ---- p1: A-h0 x W-h1        (retire A-h1(kt) for p2)
-    SEG_WAIT();
-    SEG_BARRIER();
     read_b(b1, buf + 3 * HALF);
-    if (steady) dma(srcA[0], kt + 2, 0);                    // A-h0 slot of this buffer: read in p0
+    if (kt >= 1 && !last) dma(srcA[1], kt + 1, 1);          // A-h1(kt+1): its slot was last read in P1(kt-1)
     SEG_READS_DONE();
-    SEG_COMPUTE(a, b1, 0, 1);
-    // ---- p2: A-h1 x W-h1
+    SEG_BARRIER();
+    __builtin_amdgcn_s_setprio(1);
+    mma(a, b0, 0, 0);
+    mma(a, b1, 0, 1);
+    __builtin_amdgcn_s_setprio(0);
+    // ---- P1
+    if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     SEG_BARRIER();
     read_a(a, buf + HALF);
-    if (steady) dma(srcW[0], kt + 2, 2);                    // W-h0 slot: read in p0 (kept in registers)
+    if (steady) {
+      dma(srcA[0], kt + 2, 0);
+      dma(srcW[0], kt + 2, 2);
+      dma(srcW[1], kt + 2, 3);
+    }
     SEG_READS_DONE();
-    SEG_COMPUTE(a, b1, 2, 1);
-    // ---- p3: A-h1 x W-h0, both in registers   (retire A-h0(kt+1), W-h0(kt+1) for the next p0)
-    SEG_WAIT();
     SEG_BARRIER();
-    if (steady) dma(srcW[1], kt + 2, 3);                    // W-h1 slot: read in p1
-    SEG_COMPUTE(a, b0, 2, 0);
+    __builtin_amdgcn_s_setprio(1);
+    mma(a, b1, 2, 1);
+    mma(a, b0, 2, 0);
+    __builtin_amdgcn_s_setprio(0);
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();            // balance group 1's extra barrier
-#undef SEG_WAIT
 #undef SEG_BARRIER
 #undef SEG_READS_DONE
-#undef SEG_COMPUTE
   __syncthreads();
   STAMP(2);
 
