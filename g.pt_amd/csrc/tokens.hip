@@ -117,19 +117,32 @@ __device__ __forceinline__ void mma_chunk(const char* ldsA, const char* ldsW, in
   }
 }
 
-// stage a [128 rows x KC] weight chunk (T, 16-byte aligned rows); rows >= nrows are clamped (dropped at store)
+// a [128 rows x KC] weight chunk (T, 16-byte aligned rows) = NW 16-byte vectors per thread; rows >= nrows are clamped
+// (dropped at store).  Split into a register load and an LDS store so that the global loads of chunk t+1 fly during
+// the MFMAs of chunk t (single LDS buffer, register staging).
 template <typename T>
-__device__ __forceinline__ void stage_w(const T* w, int64_t ld, int row0, int nrows, int k0, char* lds, int tid) {
-  constexpr int P = Pitch<T>::value;
-  constexpr int V = KC * sizeof(T) / 16;           // 16-byte vectors per row: 4 (bf16) / 8 (fp32)
-  for (int i = tid; i < TN * V; i += 256) {
-    const int row = i / V, c = i % V;
-    int gr = row0 + row;
-    gr = gr < nrows ? gr : nrows - 1;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(w + (int64_t)gr * ld + k0) + c * 16);
-    *reinterpret_cast<u32x4*>(lds + row * P + c * 16) = v;
+struct WStage {
+  static constexpr int V = KC * sizeof(T) / 16;   // 16-byte vectors per row: 4 (bf16) / 8 (fp32)
+  static constexpr int NW = TN * V / 256;         // per thread: 2 (bf16) / 4 (fp32)
+  u32x4 v[NW];
+  __device__ __forceinline__ void load(const T* w, int64_t ld, int row0, int nrows, int k0, int tid) {
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int i = tid + j * 256, row = i / V, c = i % V;
+      int gr = row0 + row;
+      gr = gr < nrows ? gr : nrows - 1;
+      v[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(w + (int64_t)gr * ld + k0) + c * 16);
+    }
   }
-}
+  __device__ __forceinline__ void store(char* lds, int tid) const {
+    constexpr int P = Pitch<T>::value;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int i = tid + j * 256, row = i / V, c = i % V;
+      *reinterpret_cast<u32x4*>(lds + row * P + c * 16) = v[j];
+    }
+  }
+};
 
 template <typename T>
 __global__ __launch_bounds__(256) void encode_kernel(EncArgs g) {
@@ -150,16 +163,27 @@ __global__ __launch_bounds__(256) void encode_kernel(EncArgs g) {
   const int arow = tid >> 2, acol = (tid & 3) * 8;   // 64 rows x 4 threads x 8 consecutive k
   const int gb = b0 + arow;
   const float* srow = tk.src + (int64_t)(gb < g.B ? gb : g.B - 1) * tk.src_ld;
-  for (int k0 = 0; k0 < tk.k; k0 += KC) {
-    T* dst = reinterpret_cast<T*>(ldsA + arow * P) + acol;
+  float av[8];
+  WStage<T> ws;
+  auto load_a = [&](int k0) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int k = k0 + acol + e;
-      const float v = k < tk.k ? srow[k] : 0.f;
-      elem<T>::store(dst + e, v);
+      av[e] = k < tk.k ? srow[k] : 0.f;
     }
-    stage_w<T>((const T*)tk.w, tk.w_ld, n0, g.d, k0, ldsW, tid);
+  };
+  load_a(0);
+  ws.load((const T*)tk.w, tk.w_ld, n0, g.d, 0, tid);
+  for (int k0 = 0; k0 < tk.k; k0 += KC) {
+    T* dst = reinterpret_cast<T*>(ldsA + arow * P) + acol;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) elem<T>::store(dst + e, av[e]);
+    ws.store(ldsW, tid);
     __syncthreads();
+    if (k0 + KC < tk.k) {
+      load_a(k0 + KC);
+      ws.load((const T*)tk.w, tk.w_ld, n0, g.d, k0 + KC, tid);
+    }
     mma_chunk<T>(ldsA, ldsW, wr, wc, lane, acc);
     __syncthreads();
   }
@@ -195,17 +219,33 @@ __global__ __launch_bounds__(256) void decode_kernel(DecArgs g) {
     for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
   constexpr int V = KC * sizeof(T) / 16;
+  constexpr int NA = TB * V / 256;                 // feature vectors per thread: 1 (bf16) / 2 (fp32)
   const T* feat = (const T*)g.feat;
-  for (int k0 = 0; k0 < g.d; k0 += KC) {
-    for (int i = tid; i < TB * V; i += 256) {
-      const int row = i / V, c = i % V;
+  u32x4 fv[NA];
+  WStage<T> ws;
+  auto load_f = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int i = tid + j * 256, row = i / V, c = i % V;
       int gb = b0 + row;
       gb = gb < g.B ? gb : g.B - 1;
-      const char* src = reinterpret_cast<const char*>(feat + ((int64_t)gb * g.T + blockIdx.z) * g.d + k0) + c * 16;
-      *reinterpret_cast<u32x4*>(ldsA + row * P + c * 16) = *reinterpret_cast<const u32x4*>(src);
+      fv[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(feat + ((int64_t)gb * g.T + blockIdx.z) * g.d + k0) + c * 16);
     }
-    stage_w<T>((const T*)tk.w, g.d, n0, tk.n, k0, ldsW, tid);
+  };
+  load_f(0);
+  ws.load((const T*)tk.w, g.d, n0, tk.n, 0, tid);
+  for (int k0 = 0; k0 < g.d; k0 += KC) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int i = tid + j * 256, row = i / V, c = i % V;
+      *reinterpret_cast<u32x4*>(ldsA + row * P + c * 16) = fv[j];
+    }
+    ws.store(ldsW, tid);
     __syncthreads();
+    if (k0 + KC < g.d) {
+      load_f(k0 + KC);
+      ws.load((const T*)tk.w, g.d, n0, tk.n, k0 + KC, tid);
+    }
     mma_chunk<T>(ldsA, ldsW, wr, wc, lane, acc);
     __syncthreads();
   }
