@@ -5,7 +5,7 @@
 // forward / backward kernels wrote them - no transposed copies of the activations.
 //
 // Same pipeline as gemm256.hip (8 waves as 2 x 4 of 128 x 64, two 64-KiB K-tile buffers of four 16-KiB half-tiles,
-// four phases per K-tile, LDS-DMA refills with counted vmcnt, two wave groups one barrier apart).  What differs:
+// two phases per K-tile, LDS-DMA refills with counted vmcnt, two wave groups one barrier apart).  What differs:
 //  * a K-tile is 64 ROWS r of the operands; a half-tile holds, for each of them, 128 CONTIGUOUS columns of the block
 //    tile (full 256-byte runs for the LDS-DMA) = 64 LDS rows of 256 bytes; a wave therefore owns output rows
 //    {128 hi + 64 wr + [0, 64)} and columns {128 hj + 32 wc + [0, 32)} for the halves hi, hj = 0, 1;
@@ -15,6 +15,7 @@
 //    rows of a block then sit in four different 64-byte bank groups and the read is conflict-free.
 // Needs R % 64 == 0, I % 256 == 0, J % 256 == 0 (the host falls back to transposes + the NT kernel otherwise).
 #include "gemm_common.h"
+#include <stdlib.h>
 
 namespace gemmk {
 namespace {
@@ -41,15 +42,19 @@ __device__ __forceinline__ u32x4 tr_frag(const char* base_lo, int ks) {
   return out;
 }
 
+// ksplit > 1 (accumulating epilogue only): the R range is cut into ksplit contiguous spans, one workgroup per (span, tile),
+// and every workgroup ADDS its partial tile with hardware fp32 atomics (one accumulator register = two full 128-byte
+// lines per wave instruction).  A weight gradient has few output tiles (d x d: 36, d x 4d: 144 on 256 CUs) and a very
+// long contraction (R = B*T rows), so spans fill the chip for the price of the atomics (~0.2 us per partial tile).
 template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(GemmArgs<bf16_t> g) {
+__global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(GemmArgs<bf16_t> g, int ksplit) {
   using T = bf16_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
 
-  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int nwg = gridDim.x / ksplit, span = blockIdx.x / nwg, bid = blockIdx.x - span * nwg;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
   const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   // column groups of 8 tiles, rows fastest across the group (see gemm256.hip): both strips re-used from the XCD's L2
@@ -58,7 +63,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(GemmArgs<bf16_t> g) 
   const int gb = tile / (tiles_m * GROUP_N), grem = tile - gb * (tiles_m * GROUP_N);
   const int gw = min(GROUP_N, tiles_n - gb * GROUP_N);
   const int m0 = (grem / gw) * 256, n0 = (gb * GROUP_N + grem % gw) * 256;   // output rows (P columns) / columns (Q columns)
-  const int nk = g.K / 64;
+  const int nk_all = g.K / 64, nk_span = (nk_all + ksplit - 1) / ksplit, kt0 = span * nk_span;
+  const int nk = min(nk_span, nk_all - kt0);
+  if (nk <= 0) return;                                      // workgroup-uniform
 
   // per-lane DMA sources: this wave fills LDS rows [wid*8, wid*8+8) of every half-tile (2 pieces of 4 rows);
   // lane -> (row = lane >> 4, chunk = lane & 15) of the piece, the chunk's logical position un-swizzled
@@ -75,8 +82,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(GemmArgs<bf16_t> g) 
       srcP[h][p] = g.A + (int64_t)(m0 % 64 + wid * 16 + p * 8 + (lane >> 3)) * g.lda + (lane & 7) * 8 + h * 64;
       srcQ[h][p] = g.W + (int64_t)(n0 % 64 + wid * 16 + p * 8 + (lane >> 3)) * g.ldw + (lane & 7) * 8 + h * 64;
 #else
-      srcP[h][p] = g.A + (int64_t)lr * g.lda + m0 + h * 128 + e;
-      srcQ[h][p] = g.W + (int64_t)lr * g.ldw + n0 + h * 128 + e;
+      srcP[h][p] = g.A + ((int64_t)kt0 * 64 + lr) * g.lda + m0 + h * 128 + e;
+      srcQ[h][p] = g.W + ((int64_t)kt0 * 64 + lr) * g.ldw + n0 + h * 128 + e;
 #endif
     }
   }
@@ -122,11 +129,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(GemmArgs<bf16_t> g) 
         acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i][ks]),
                                                                 __builtin_bit_cast(bf16x8, b[ks]), acc[i0 + i][j], 0, 0, 0);
   };
-#define SEG_WAIT()                                                          \
-  do {                                                                      \
-    if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   \
-  } while (0)
 #define SEG_BARRIER()                        \
   do {                                       \
     __builtin_amdgcn_sched_barrier(0);       \
@@ -134,25 +136,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(GemmArgs<bf16_t> g) 
     __builtin_amdgcn_sched_barrier(0);       \
   } while (0)
 #define SEG_READS_DONE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#define SEG_COMPUTE(A_, B_, I0, J)           \
-  do {                                       \
-    SEG_BARRIER();                           \
-    __builtin_amdgcn_s_setprio(1);           \
-    mma(A_, B_, I0, J);                      \
-    __builtin_amdgcn_s_setprio(0);           \
-  } while (0)
 
-  // the first two half-tiles (h0 of both operands of K-tile 0) have landed: all but the 6 (one K-tile: 2) half-tiles issued after them
-  if (nk >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  // two phases of 32 MFMAs per K-tile, waits and refills exactly as in gemm256.hip:
+  //   P0: reads P-h0, Q-h0, Q-h1 -> (P-h0 x Q-h0), (P-h0 x Q-h1); refills P-h1(kt+1)
+  //   P1: reads P-h1             -> (P-h1 x Q-h1), (P-h1 x Q-h0); refills P-h0, Q-h0, Q-h1 (kt+2)
+  if (nk >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   if (wr == 1) __builtin_amdgcn_s_barrier();
 
   for (int kt = 0; kt < nk; ++kt) {
     const char* buf = smem + (kt & 1) * TBUF;
-    const bool steady = kt + 2 < nk;
+    const bool steady = kt + 2 < nk, last = kt + 1 == nk;
     u32x4 a[2][4], b0[4], b1[4];
-    // ---- p0: P-h0 x Q-h0
-    SEG_WAIT();
+    // ---- P0
+    if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     SEG_BARRIER();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) b0[ks] = tr_frag(buf + 2 * THALF + offQ, ks);
@@ -160,37 +158,38 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(GemmArgs<bf16_t> g) 
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) a[i][ks] = tr_frag(buf + offP[i], ks);
-    if (kt >= 1 && kt + 1 < nk) dma(srcP[1], stepP, kt + 1, 1);
-    SEG_READS_DONE();
-    SEG_COMPUTE(a, b0, 0, 0);
-    // ---- p1: P-h0 x Q-h1
-    SEG_WAIT();
-    SEG_BARRIER();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) b1[ks] = tr_frag(buf + 3 * THALF + offQ, ks);
-    if (steady) dma(srcP[0], stepP, kt + 2, 0);
+    if (kt >= 1 && !last) dma(srcP[1], stepP, kt + 1, 1);
     SEG_READS_DONE();
-    SEG_COMPUTE(a, b1, 0, 1);
-    // ---- p2: P-h1 x Q-h1
+    SEG_BARRIER();
+    __builtin_amdgcn_s_setprio(1);
+    mma(a, b0, 0, 0);
+    mma(a, b1, 0, 1);
+    __builtin_amdgcn_s_setprio(0);
+    // ---- P1
+    if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     SEG_BARRIER();
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) a[i][ks] = tr_frag(buf + THALF + offP[i], ks);
-    if (steady) dma(srcQ[0], stepQ, kt + 2, 2);
+    if (steady) {
+      dma(srcP[0], stepP, kt + 2, 0);
+      dma(srcQ[0], stepQ, kt + 2, 2);
+      dma(srcQ[1], stepQ, kt + 2, 3);
+    }
     SEG_READS_DONE();
-    SEG_COMPUTE(a, b1, 2, 1);
-    // ---- p3: P-h1 x Q-h0, both in registers
-    SEG_WAIT();
     SEG_BARRIER();
-    if (steady) dma(srcQ[1], stepQ, kt + 2, 3);
-    SEG_COMPUTE(a, b0, 2, 0);
+    __builtin_amdgcn_s_setprio(1);
+    mma(a, b1, 2, 1);
+    mma(a, b0, 2, 0);
+    __builtin_amdgcn_s_setprio(0);
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
-#undef SEG_WAIT
 #undef SEG_BARRIER
 #undef SEG_READS_DONE
-#undef SEG_COMPUTE
   __syncthreads();
 
   // epilogue straight from the accumulator layout (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)):
@@ -201,7 +200,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(GemmArgs<bf16_t> g) 
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       float* c = (float*)g.C + (int64_t)(m0 + (i >> 1) * 128 + wr * 64 + (i & 1) * 32 + 4 * fh) * g.ldc + n0 + j * 128 + wc * 32 + fr;
-      if constexpr (EPI == GPT_EPI_ACCUM_F32) {
+      if (EPI == GPT_EPI_ACCUM_F32 && ksplit > 1) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) unsafeAtomicAdd(c + (int64_t)((e & 3) + 8 * (e >> 2)) * g.ldc, acc[i][j][e]);
+      } else if constexpr (EPI == GPT_EPI_ACCUM_F32) {
         float old[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) old[e] = c[(int64_t)((e & 3) + 8 * (e >> 2)) * g.ldc];
@@ -226,9 +228,30 @@ int launch_tn(const GemmArgs<bf16_t>& g, hipStream_t s) {
     attr_set = true;
   }
   const int tiles = (g.M / 256) * (g.N / 256);
+  // spans: estimated time (us) = rounds x (K-tiles per span x 1.5 + 10) + atomics at ~0.2 us per partial tile and CU round
+  int ksplit = 1;
+  if (EPI == GPT_EPI_ACCUM_F32) {
+    static const int n_cu = [] {
+      int dev = 0, n = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+      return n > 0 ? n : 256;
+    }();
+    static const int forced = [] {
+      const char* e = getenv("GPT_TN_KSPLIT");   // experiments: force a span count (0 = model)
+      return e ? atoi(e) : 0;
+    }();
+    const int nk_all = g.K / 64;
+    double best = 1e30;
+    for (int sp = 1; sp <= 16 && sp * 8 <= nk_all; ++sp) {
+      const int wgs = tiles * sp, rounds = (wgs + n_cu - 1) / n_cu, per = (nk_all + sp - 1) / sp;
+      const double t = rounds * (per * 1.5 + 10.0) + (sp > 1 ? 0.2 * wgs : 0.0);
+      if (t < best) { best = t; ksplit = sp; }
+    }
+    if (forced > 0) ksplit = forced;
+  }
   const bool rec = g_prof.on && g_prof.n < GemmProf::CAP;
   if (rec) (void)hipEventRecord(g_prof.ev[g_prof.n][0], s);
-  hipLaunchKernelGGL((gemm256_tn_kernel<EPI>), dim3(tiles), dim3(512), TLDS_BYTES, s, g);
+  hipLaunchKernelGGL((gemm256_tn_kernel<EPI>), dim3(tiles * ksplit), dim3(512), TLDS_BYTES, s, g, ksplit);
   if (rec) {
     (void)hipEventRecord(g_prof.ev[g_prof.n][1], s);
     g_prof.flops[g_prof.n++] = 2.0 * g.M * g.N * g.K;

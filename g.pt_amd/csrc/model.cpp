@@ -143,8 +143,8 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
     return !e || atoi(e) != 0;
   }();
   auto wgrad = [&](const void* dY, int n_out, const void* X, int k_in, float* gW) -> int {
-    // the TN kernel only has 256 x 256 tiles: with few of them (d x d weights) transposes + the finer ring kernels win (r01 bench)
-    if (use_tn && dt == GPT_BF16 && M % 64 == 0 && n_out % 256 == 0 && k_in % 256 == 0 && (n_out / 256) * (k_in / 256) >= 96)
+    // the TN kernel cuts the row range into spans when the weight has few 256 x 256 tiles (gemm256_tn.hip)
+    if (use_tn && dt == GPT_BF16 && M % 64 == 0 && n_out % 256 == 0 && k_in % 256 == 0)
       return gpt_gemm_tn(dY, n_out, X, k_in, gW, k_in, n_out, k_in, M, 1, stream);
     CHECK(gpt_transpose(dt, dY, bw->tA, M, n_out, Mp, stream));
     CHECK(gpt_transpose(dt, X, bw->tB, M, k_in, Mp, stream));
