@@ -18,9 +18,10 @@
 // LDS per workgroup is 72 KiB (big, 3 stages) / 64 KiB (small, 4 stages): TWO workgroups are resident per CU,
 // so one workgroup's epilogue (global stores, residual read-modify-write) overlaps the other's main loop.
 //
-// Bank conflicts: 64-byte LDS rows; the 16-byte chunk c of row r is stored at chunk c ^ ((r >> 2) & 3) (applied
-// on the per-lane DMA SOURCE address and again on the ds_read_b128 address): conflict-free for the
-// 16-lane groups of ds_read_b128.
+// Bank conflicts: 64-byte LDS rows; the 16-byte chunk c of row r is stored at chunk c ^ swz(r) (applied on the
+// per-lane DMA SOURCE address and again on the ds_read_b128 address): conflict-free for the 16-lane groups of
+// ds_read_b128 under each dtype's fragment shape (fp32, 32x32x2: rows lane & 31, swz = (r >> 2) & 3;
+// bf16, 16x16x32: rows lane & 15 and chunk lane >> 4, swz = (-(r >> 2)) & 3).
 //
 // Epilogue: each wave passes its accumulators through a private 4 KiB LDS patch, 32 x 32 at a time, so
 // that global accesses are 16-byte (fp32) / 8-byte (bf16) row vectors; no workgroup barrier is involved.
@@ -38,6 +39,12 @@ using namespace gemmk;
 
 constexpr int ROWB = 64;  // bytes of K per staged row
 
+template <typename T>
+__device__ __forceinline__ int swz(int r) {
+  if constexpr (sizeof(T) == 2) return (0 - (r >> 2)) & 3;
+  else return (r >> 2) & 3;
+}
+
 // LDS-DMA of NP 1-KiB pieces (16 rows x 64 B each) of an operand panel
 template <typename T, int NP>
 __device__ __forceinline__ void stage_rows(const T* __restrict__ base, int64_t ld, int row0, int nrows_total, int k0,
@@ -47,7 +54,7 @@ __device__ __forceinline__ void stage_rows(const T* __restrict__ base, int64_t l
   for (int i = 0; i < NP; ++i) {
     const int piece = first_piece + i;
     const int rr = piece * 16 + (lane >> 2);
-    const int lc = (lane & 3) ^ ((rr >> 2) & 3);
+    const int lc = (lane & 3) ^ swz<T>(rr);
     int grow = row0 + rr;
     grow = grow < nrows_total ? grow : nrows_total - 1;  // clamp: rows past the edge are computed and dropped
     const T* src = base + (int64_t)grow * ld + k0 + lc * EPC;
@@ -55,8 +62,9 @@ __device__ __forceinline__ void stage_rows(const T* __restrict__ base, int64_t l
   }
 }
 
+template <typename T>
 __device__ __forceinline__ u32x4 read_frag(const char* lds_tile, int row, int lc) {
-  const int off = row * ROWB + ((lc ^ ((row >> 2) & 3)) << 4);
+  const int off = row * ROWB + ((lc ^ swz<T>(row)) << 4);
   return *reinterpret_cast<const u32x4*>(lds_tile + off);
 }
 
@@ -84,13 +92,24 @@ __global__ __launch_bounds__(WM * 128, WM) void gemm_nt_kernel(GemmArgs<T> g) {
   constexpr int BK = ROWB / sizeof(T);
   const int nk = g.K / BK;
 
-  f32x16 acc[2][2];
+  // bf16: 16x16x32 MFMAs (one per 64-byte K-step and 16 x 16 tile; higher sustained clock than 32x32x16, see gemm256.hip),
+  // 4 x 4 accumulator tiles;  fp32: 32x32x2, 2 x 2 tiles
+  constexpr bool M16 = sizeof(T) == 2;
+  f32x4 acc16[M16 ? 4 : 1][M16 ? 4 : 1];
+  f32x16 acc[M16 ? 1 : 2][M16 ? 1 : 2];
+  if constexpr (M16) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  } else {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  }
 
   auto stage = [&](int kt) {
     char* buf = smem + (kt % NSTAGE) * STAGE_BYTES;
@@ -101,7 +120,7 @@ __global__ __launch_bounds__(WM * 128, WM) void gemm_nt_kernel(GemmArgs<T> g) {
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) stage(s);
 
-  const int fr = lane & 31, fh = lane >> 5;
+  const int fr = lane & 31, fh = lane >> 5, l15 = lane & 15, l4 = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     // K-tile kt has landed once at most the pieces of the tiles issued after it are pending
     const int ahead = nk - 1 - kt < NSTAGE - 2 ? nk - 1 - kt : NSTAGE - 2;
@@ -112,39 +131,56 @@ __global__ __launch_bounds__(WM * 128, WM) void gemm_nt_kernel(GemmArgs<T> g) {
     if (kt + NSTAGE - 1 < nk) stage(kt + NSTAGE - 1);
     const char* bufA = smem + (kt % NSTAGE) * STAGE_BYTES;
     const char* bufW = bufA + BM * ROWB;
+    if constexpr (M16) {
+      u32x4 a[4], b[4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      u32x4 a[2], b[2];
+      for (int i = 0; i < 4; ++i) a[i] = read_frag<T>(bufA, wr * 64 + i * 16 + l15, l4);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = read_frag(bufA, wr * 64 + i * 32 + fr, 2 * ks + fh);
+      for (int j = 0; j < 4; ++j) b[j] = read_frag<T>(bufW, wc * 64 + j * 16 + l15, l4);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = read_frag(bufW, wc * 64 + j * 32 + fr, 2 * ks + fh);
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j)
+          acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]),
+                                                                acc16[i][j], 0, 0, 0);
+    } else {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if constexpr (sizeof(T) == 2) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                __builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
-          } else {
-            // 16 bytes = 4 fp32 k-values per lane half; element e of both halves forms one K=2 step
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 a[2], b[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+        for (int i = 0; i < 2; ++i) a[i] = read_frag<T>(bufA, wr * 64 + i * 32 + fr, 2 * ks + fh);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = read_frag<T>(bufW, wc * 64 + j * 32 + fr, 2 * ks + fh);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)   // 16 bytes = 4 fp32 k-values per lane half; element e of both halves forms one K=2 step
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[i][e]), __uint_as_float(b[j][e]),
                                                                acc[i][j], 0, 0, 0);
-          }
-        }
+      }
     }
   }
   __syncthreads();  // every wave is done reading the last stage before the epilogue patches overwrite LDS
 
-  // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   float* patch = reinterpret_cast<float*>(smem + wid * PATCH_BYTES);
   auto to_patch = [&](int step) {
+    if constexpr (M16) {
+      // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + 4 * fh) * PATCH_PITCH + j * 32 + fr] = acc[step][j][e];
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) patch[(ii * 16 + 4 * l4 + e) * PATCH_PITCH + jt * 16 + l15] = acc16[2 * step + ii][jt][e];
+    } else {
+      // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + 4 * fh) * PATCH_PITCH + j * 32 + fr] = acc[step][j][e];
+    }
   };
   epilogue_wave<T, EPI, 2>(g, to_patch, patch, m0 + wr * 64, n0 + wc * 64, lane);
 }
