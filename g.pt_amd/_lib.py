@@ -70,6 +70,7 @@ _PROTOS = {
                            vp], i32),
     "gpt_q_sample": ([vp, vp, vp, vp, vp, i32, i32, vp], i32),
     "gpt_posterior_step": ([vp, vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, i32, i32, vp], i32),
+    "gpt_ddim_step": ([vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, vp, vp, i32, i32, vp], i32),
     "gpt_mse_rows": ([vp, vp, vp, i32, i32, vp], i32),
     "gpt_mse_rows_bwd": ([vp, vp, vp, vp, i32, i32, vp], i32),
     "gpt_randn": ([vp, i64, u64, u64, vp], i32),
@@ -97,6 +98,8 @@ _PROTOS = {
     "gpt_pack_segments": ([vp, vp, i32, vp, i32, i64, vp], i32),
     "gpt_sample_loop": ([C.POINTER(Model), C.POINTER(Workspace), vp, vp, vp, i32, vp, vp, C.POINTER(i64), i32, i32,
                          i32, i32, i32, f32, f32, vp, u64, vp, vp, vp, vp, i32, vp], i32),
+    "gpt_ddim_sample_loop": ([C.POINTER(Model), C.POINTER(Workspace), vp, vp, vp, i32, vp, vp, vp, f32, C.POINTER(i64), i32,
+                              i32, i32, i32, i32, f32, f32, vp, u64, vp, vp, vp, vp, i32, vp], i32),
 }
 
 _lib = None

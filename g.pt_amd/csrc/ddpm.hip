@@ -96,6 +96,56 @@ __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict_
   }
 }
 
+// DDIM step (gaussian_diffusion.py:507-552).  Every scalar is formed in fp32 from the fp32-rounded tables with the
+// reference's own operation order (sqrt and division are IEEE here; contraction is off in this file), so the update is
+// bit-exact against the same arithmetic on the CPU:
+//   eps    = (recip[t] x_t - x0) / recipm1[t]
+//   sigma  = eta * sqrt((1 - abp) / (1 - ab)) * sqrt(1 - ab / abp)         ab = alphas_cumprod[t], abp = alphas_cumprod[t - 1] | 1
+//   x_prev = x0 sqrt(abp) + sqrt(1 - abp - sigma^2) eps + (t != 0) sigma noise
+struct DdimScal {
+  float recip, recipm1, sq_abp, dir, sigma, mask;
+};
+
+template <int V>
+__global__ __launch_bounds__(256) void ddim_kernel(const float* __restrict__ mo, const float* __restrict__ xt,
+                                                   const float* __restrict__ noise, const int64_t* __restrict__ t,
+                                                   const float* __restrict__ coef, const float* __restrict__ acp,
+                                                   int predict_xstart, int use_clamp, float lo, float hi, float eta,
+                                                   float* __restrict__ xout, float* __restrict__ x0out, int B, int DV) {
+  const int b = blockIdx.y;
+  const int64_t tb = t[b];
+  DdimScal p;
+  p.recip = coef[tb * NC + GPT_C_RECIP];
+  p.recipm1 = coef[tb * NC + GPT_C_RECIPM1];
+  const float ab = acp[tb], abp = tb > 0 ? acp[tb - 1] : 1.0f;
+  p.sigma = (eta * sqrtf((1.0f - abp) / (1.0f - ab))) * sqrtf(1.0f - ab / abp);
+  p.sq_abp = sqrtf(abp);
+  p.dir = sqrtf((1.0f - abp) - p.sigma * p.sigma);
+  p.mask = tb != 0 ? 1.0f : 0.0f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < DV; i += gridDim.x * blockDim.x) {
+    const int64_t o = ((int64_t)b * DV + i) * V;
+    const vec<V> m = vload<V>(mo + o), x = vload<V>(xt + o);
+    vec<V> n;
+    if (noise) n = vload<V>(noise + o);
+    else {
+#pragma unroll
+      for (int e = 0; e < V; ++e) n.v[e] = 0.f;
+    }
+    vec<V> r, z;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float x0 = predict_xstart ? m.v[e] : p.recip * x.v[e] - p.recipm1 * m.v[e];
+      if (use_clamp) x0 = fminf(fmaxf(x0, lo), hi);
+      z.v[e] = x0;
+      const float eps = (p.recip * x.v[e] - x0) / p.recipm1;
+      const float mean = x0 * p.sq_abp + p.dir * eps;
+      r.v[e] = mean + (p.mask * p.sigma) * n.v[e];
+    }
+    vstore<V>(xout + o, r);
+    if (x0out) vstore<V>(x0out + o, z);
+  }
+}
+
 // one 256-thread block per sample row
 __global__ __launch_bounds__(256) void mse_rows_kernel(const float* __restrict__ target, const float* __restrict__ out,
                                                        float* __restrict__ mse, int D) {
@@ -235,6 +285,27 @@ extern "C" int gpt_posterior_step(const float* model_out, const float* x_t, cons
   else POST(1);
 #undef POST
   return gpt_launch_status("gpt_posterior_step");
+}
+
+extern "C" int gpt_ddim_step(const float* model_out, const float* x_t, const float* noise, const int64_t* t,
+                             const float* coef, const float* alphas_cumprod, int predict_xstart, int use_clamp, float lo,
+                             float hi, float eta, float* x_out, float* pred_xstart, int B, int D, void* stream) {
+  GPT_REQUIRE(model_out && x_t && t && coef && alphas_cumprod && x_out, "gpt_ddim_step: null operand");
+  GPT_REQUIRE(B > 0 && D > 0, "gpt_ddim_step: empty problem (B=%d D=%d)", B, D);
+  GPT_REQUIRE(eta >= 0.f, "gpt_ddim_step: eta must be >= 0");
+  GPT_REQUIRE(noise || eta == 0.f, "gpt_ddim_step: eta > 0 needs noise");
+  const int V = vec_width(D, model_out, x_t, noise, x_out, pred_xstart);
+  const int gx = blocks_for(D / V) > 8 ? 8 : blocks_for(D / V);
+  const dim3 grid(gx, B);
+  hipStream_t s = (hipStream_t)stream;
+#define DDIM(VV)                                                                                                       \
+  hipLaunchKernelGGL(ddim_kernel<VV>, grid, dim3(256), 0, s, model_out, x_t, noise, t, coef, alphas_cumprod,             \
+                     predict_xstart, use_clamp, lo, hi, eta, x_out, pred_xstart, B, D / VV)
+  if (V == 4) DDIM(4);
+  else if (V == 2) DDIM(2);
+  else DDIM(1);
+#undef DDIM
+  return gpt_launch_status("gpt_ddim_step");
 }
 
 extern "C" int gpt_mse_rows(const float* target, const float* out, float* mse, int B, int D, void* stream) {

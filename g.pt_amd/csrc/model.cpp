@@ -90,28 +90,60 @@ extern "C" int gpt_denoiser_forward(const gpt_model_t* m, const gpt_workspace_t*
   return 0;
 }
 
+// ddim: 0 = ancestral DDPM step (gpt_posterior_step), 1 = DDIM step with `eta` (gpt_ddim_step, needs alphas_cumprod)
+static int sample_loop(const char* who, int ddim, float eta, const float* alphas_cumprod, const gpt_model_t* m,
+                       const gpt_workspace_t* ws, float* x, const void* loss_target, const void* loss_prev, int loss_is_f64,
+                       const float* x_prev, const float* coef, const int64_t* host_timestep_map, int n_steps, int first_step,
+                       int last_step, int predict_xstart, int use_clamp, float lo, float hi, const float* noise,
+                       uint64_t seed, int64_t* t_model, int64_t* t_index, float* model_out, float* noise_buf, int B,
+                       void* stream) {
+  CHECK(validate(m, ws, B, who));
+  GPT_REQUIRE(x && coef && host_timestep_map && t_model && t_index && model_out, "%s: null operand", who);
+  const bool need_noise = !ddim || eta != 0.f;
+  GPT_REQUIRE(!need_noise || noise || noise_buf, "%s: need injected noise or a noise scratch buffer", who);
+  GPT_REQUIRE(!ddim || alphas_cumprod, "%s: null alphas_cumprod", who);
+  GPT_REQUIRE(n_steps > 0 && first_step < n_steps && last_step >= 0 && first_step >= last_step,
+              "%s: bad step range [%d..%d] of %d", who, first_step, last_step, n_steps);
+  GPT_REQUIRE(ws->layer_stride == 0, "%s: needs an inference workspace", who);
+  const int64_t BD = (int64_t)B * m->D;
+  for (int i = first_step; i >= last_step; --i) {
+    CHECK(gpt_fill_i64(t_index, B, i, stream));
+    CHECK(gpt_fill_i64(t_model, B, host_timestep_map[i], stream));
+    CHECK(gpt_denoiser_forward(m, ws, x, t_model, loss_target, loss_prev, loss_is_f64, x_prev, model_out, B, stream));
+    const float* nz = nullptr;
+    if (need_noise) {
+      nz = noise ? noise + (int64_t)i * BD : noise_buf;
+      if (!noise) CHECK(gpt_randn(noise_buf, BD, seed, (uint64_t)i, stream));
+    }
+    if (ddim)
+      CHECK(gpt_ddim_step(model_out, x, nz, t_index, coef, alphas_cumprod, predict_xstart, use_clamp, lo, hi, eta, x, nullptr,
+                          B, m->D, stream));
+    else
+      CHECK(gpt_posterior_step(model_out, x, nz, t_index, coef, predict_xstart, use_clamp, lo, hi, x, nullptr, B, m->D, stream));
+  }
+  return 0;
+}
+
 extern "C" int gpt_sample_loop(const gpt_model_t* m, const gpt_workspace_t* ws, float* x, const void* loss_target,
                                const void* loss_prev, int loss_is_f64, const float* x_prev, const float* coef,
                                const int64_t* host_timestep_map, int n_steps, int first_step, int last_step,
                                int predict_xstart, int use_clamp, float lo, float hi, const float* noise, uint64_t seed,
                                int64_t* t_model, int64_t* t_index, float* model_out, float* noise_buf, int B,
                                void* stream) {
-  CHECK(validate(m, ws, B, "gpt_sample_loop"));
-  GPT_REQUIRE(x && coef && host_timestep_map && t_model && t_index && model_out, "gpt_sample_loop: null operand");
-  GPT_REQUIRE(noise || noise_buf, "gpt_sample_loop: need injected noise or a noise scratch buffer");
-  GPT_REQUIRE(n_steps > 0 && first_step < n_steps && last_step >= 0 && first_step >= last_step,
-              "gpt_sample_loop: bad step range [%d..%d] of %d", first_step, last_step, n_steps);
-  GPT_REQUIRE(ws->layer_stride == 0, "gpt_sample_loop: needs an inference workspace");
-  const int64_t BD = (int64_t)B * m->D;
-  for (int i = first_step; i >= last_step; --i) {
-    CHECK(gpt_fill_i64(t_index, B, i, stream));
-    CHECK(gpt_fill_i64(t_model, B, host_timestep_map[i], stream));
-    CHECK(gpt_denoiser_forward(m, ws, x, t_model, loss_target, loss_prev, loss_is_f64, x_prev, model_out, B, stream));
-    const float* nz = noise ? noise + (int64_t)i * BD : noise_buf;
-    if (!noise) CHECK(gpt_randn(noise_buf, BD, seed, (uint64_t)i, stream));
-    CHECK(gpt_posterior_step(model_out, x, nz, t_index, coef, predict_xstart, use_clamp, lo, hi, x, nullptr, B, m->D, stream));
-  }
-  return 0;
+  return sample_loop("gpt_sample_loop", 0, 0.f, nullptr, m, ws, x, loss_target, loss_prev, loss_is_f64, x_prev, coef,
+                     host_timestep_map, n_steps, first_step, last_step, predict_xstart, use_clamp, lo, hi, noise, seed, t_model,
+                     t_index, model_out, noise_buf, B, stream);
+}
+
+extern "C" int gpt_ddim_sample_loop(const gpt_model_t* m, const gpt_workspace_t* ws, float* x, const void* loss_target,
+                                    const void* loss_prev, int loss_is_f64, const float* x_prev, const float* coef,
+                                    const float* alphas_cumprod, float eta, const int64_t* host_timestep_map, int n_steps,
+                                    int first_step, int last_step, int predict_xstart, int use_clamp, float lo, float hi,
+                                    const float* noise, uint64_t seed, int64_t* t_model, int64_t* t_index, float* model_out,
+                                    float* noise_buf, int B, void* stream) {
+  return sample_loop("gpt_ddim_sample_loop", 1, eta, alphas_cumprod, m, ws, x, loss_target, loss_prev, loss_is_f64, x_prev, coef,
+                     host_timestep_map, n_steps, first_step, last_step, predict_xstart, use_clamp, lo, hi, noise, seed, t_model,
+                     t_index, model_out, noise_buf, B, stream);
 }
 
 extern "C" int gpt_denoiser_backward(const gpt_model_t* m, const gpt_workspace_t* ws, const gpt_backward_t* bw,

@@ -310,7 +310,8 @@ class GaussianDiffusion:
     def _timestep_map(self):
         return list(range(self.num_timesteps))
 
-    def _fused_loop(self, gpt, shape, noise, clip_denoised, denoised_fn, model_kwargs, device, step_noise, seed):
+    def _fused_loop(self, gpt, shape, noise, clip_denoised, denoised_fn, model_kwargs, device, step_noise, seed,
+                    ddim_eta=None):
         self._check_types()
         dev = torch.device(device) if device is not None else next(gpt.parameters()).device
         if dev.type != "cuda":
@@ -340,11 +341,19 @@ class GaussianDiffusion:
             noise_buf = torch.empty_like(x)
             if seed is None:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        L.check(L.lib().gpt_sample_loop(
-            C.byref(eng.cmodel), C.byref(ws), L.ptr(x), L.ptr(lt), L.ptr(lp), int(lt.dtype == torch.float64), L.ptr(xp),
-            L.ptr(self.coef_table(dev)), tmap, n, n - 1, 0, int(self.model_mean_type == ModelMeanType.START_X),
-            int(clamp is not None), lo, hi, L.ptr(step_noise), int(seed or 0), L.ptr(t_model), L.ptr(t_index),
-            L.ptr(model_out), L.ptr(noise_buf), B, L.stream()), "gpt_sample_loop")
+        px = int(self.model_mean_type == ModelMeanType.START_X)
+        if ddim_eta is None:
+            L.check(L.lib().gpt_sample_loop(
+                C.byref(eng.cmodel), C.byref(ws), L.ptr(x), L.ptr(lt), L.ptr(lp), int(lt.dtype == torch.float64), L.ptr(xp),
+                L.ptr(self.coef_table(dev)), tmap, n, n - 1, 0, px,
+                int(clamp is not None), lo, hi, L.ptr(step_noise), int(seed or 0), L.ptr(t_model), L.ptr(t_index),
+                L.ptr(model_out), L.ptr(noise_buf), B, L.stream()), "gpt_sample_loop")
+        else:
+            L.check(L.lib().gpt_ddim_sample_loop(
+                C.byref(eng.cmodel), C.byref(ws), L.ptr(x), L.ptr(lt), L.ptr(lp), int(lt.dtype == torch.float64), L.ptr(xp),
+                L.ptr(self.coef_table(dev)), L.ptr(self._ac_table(dev)), ddim_eta, tmap, n, n - 1, 0, px,
+                int(clamp is not None), lo, hi, L.ptr(step_noise), int(seed or 0), L.ptr(t_model), L.ptr(t_index),
+                L.ptr(model_out), L.ptr(noise_buf), B, L.stream()), "gpt_ddim_sample_loop")
         return x.view(*shape)
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
@@ -368,25 +377,54 @@ class GaussianDiffusion:
                 yield out
                 img = out["sample"]
 
-    # ---- DDIM (gaussian_diffusion.py:507-674): the x0 prediction comes from the fused path, the update is
-    # elementwise torch on the GPU for now (next)
-    def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, eta=0.0):
+    # ---- DDIM (gaussian_diffusion.py:507-674): fused step kernel, and the whole loop in one
+    # host call when the model is a Gpt
+    def _ac_table(self, device):
+        key = "ac:" + str(device)
+        tab = self._coef_cache.get(key)
+        if tab is None:
+            tab = self._coef_cache[key] = torch.from_numpy(self.alphas_cumprod).float().contiguous().to(device)
+        return tab
+
+    def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, eta=0.0,
+                    noise=None):
+        """One DDIM step (gaussian_diffusion.py:507-552).  `noise` (extension): the N(0,1) draw of this step, for parity runs."""
         if cond_fn is not None:
             raise NotImplementedError("cond_fn guidance is never used by G.pt and is not on the HIP path")
-        out = self.p_mean_variance(model, x, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn,
-                                   model_kwargs=model_kwargs)
-        t = t.long()
-        eps = self._predict_eps_from_xstart(x, t, out["pred_xstart"])
-        ab = torch.from_numpy(self.alphas_cumprod).to(x.device)[t].float()[:, None]
-        abp = torch.from_numpy(self.alphas_cumprod_prev).to(x.device)[t].float()[:, None]
-        sigma = eta * torch.sqrt((1 - abp) / (1 - ab)) * torch.sqrt(1 - ab / abp)
-        noise = torch.randn_like(x)
-        mean_pred = out["pred_xstart"] * torch.sqrt(abp) + torch.sqrt(1 - abp - sigma ** 2) * eps
-        mask = (t != 0).float()[:, None]
-        return {"sample": mean_pred + mask * sigma * noise, "pred_xstart": out["pred_xstart"]}
+        self._check_types()
+        if model_kwargs is None:
+            model_kwargs = {}
+        assert t.shape == (x.shape[0],)
+        x = x.detach().float().contiguous()
+        t = t.long().contiguous()
+        model_output = model(x, t, **model_kwargs)
+        if isinstance(model_output, tuple):
+            model_output = model_output[0]
+        model_output = model_output.detach().float().contiguous()
+        model_output, clamp, is_x0 = self._apply_denoised_fn(model_output, x, t, clip_denoised, denoised_fn)
+        if noise is None:
+            noise = torch.randn_like(x)          # drawn at every step, as the reference does (:539)
+        B, D = x.shape[0], x[0].numel()
+        out, x0 = torch.empty_like(x), torch.empty_like(x)
+        lo, hi = clamp if clamp is not None else (0.0, 0.0)
+        L.check(L.lib().gpt_ddim_step(
+            L.ptr(model_output), L.ptr(x), L.ptr(noise.detach().float().contiguous()), L.ptr(t),
+            L.ptr(self.coef_table(x.device)), L.ptr(self._ac_table(x.device)), int(is_x0), int(clamp is not None), lo, hi,
+            float(eta), L.ptr(out), L.ptr(x0), B, D, L.stream()), "gpt_ddim_step")
+        return {"sample": out, "pred_xstart": x0}
 
     def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
-                         model_kwargs=None, device=None, progress=False, eta=0.0):
+                         model_kwargs=None, device=None, progress=False, eta=0.0, step_noise=None, seed=None):
+        """gaussian_diffusion.py:594-628.  Fused into one host call (gpt_ddim_sample_loop) under the same conditions as
+        p_sample_loop; `step_noise` / `seed` as there."""
+        gpt, _ = _unwrap(model)
+        fusable = (gpt is not None and cond_fn is None and not progress
+                   and (denoised_fn is None or isinstance(denoised_fn, StaticThreshold))
+                   and model_kwargs is not None and {"loss_target", "loss_prev", "x_prev"} <= set(model_kwargs)
+                   and not (gpt.training and gpt.decoder.dropout_p > 0))
+        if fusable:
+            return self._fused_loop(gpt, shape, noise, clip_denoised, denoised_fn, model_kwargs, device, step_noise, seed,
+                                    ddim_eta=float(eta))
         final = None
         for sample in self.ddim_sample_loop_progressive(model, shape, noise=noise, clip_denoised=clip_denoised,
                                                         denoised_fn=denoised_fn, cond_fn=cond_fn,
@@ -463,6 +501,9 @@ class SpacedDiffusion(GaussianDiffusion):
 
     def p_sample(self, model, *args, **kwargs):
         return super().p_sample(self._wrap_model(model), *args, **kwargs)
+
+    def ddim_sample(self, model, *args, **kwargs):
+        return super().ddim_sample(self._wrap_model(model), *args, **kwargs)
 
     def training_losses(self, model, *args, **kwargs):
         return super().training_losses(self._wrap_model(model), *args, **kwargs)

@@ -123,6 +123,15 @@ int gpt_posterior_step(const float* model_out, const float* x_t, const float* no
                        const float* coef, int predict_xstart, int use_clamp, float lo, float hi,
                        float* x_out, float* pred_xstart, int B, int D, void* stream);
 
+/* One DDIM step, fused (gaussian_diffusion.py:507-552): x0 as in gpt_posterior_step, then
+ *   eps    = (recip[t] x_t - x0) / recipm1[t]
+ *   sigma  = eta sqrt((1 - abp) / (1 - ab)) sqrt(1 - ab / abp),  ab = alphas_cumprod[t], abp = alphas_cumprod[t-1] (1 at t = 0)
+ *   x_prev = x0 sqrt(abp) + sqrt(1 - abp - sigma^2) eps + (t != 0) sigma noise
+ * alphas_cumprod: device fp32 [n_steps] (the float64 table rounded once).  noise may be NULL when eta == 0. */
+int gpt_ddim_step(const float* model_out, const float* x_t, const float* noise, const int64_t* t, const float* coef,
+                  const float* alphas_cumprod, int predict_xstart, int use_clamp, float lo, float hi, float eta,
+                  float* x_out, float* pred_xstart, int B, int D, void* stream);
+
 /* mse[b] = mean_d (target - out)^2   (diffusion_utils.py:8-12 over gaussian_diffusion.py:773) */
 int gpt_mse_rows(const float* target, const float* out, float* mse, int B, int D, void* stream);
 /* grad_out[b, :] = scale[b] * 2 (out - target) / D     (backward of the above; scale = dL/dmse) */
@@ -280,6 +289,15 @@ int gpt_sample_loop(const gpt_model_t* m, const gpt_workspace_t* ws, float* x, c
                     int predict_xstart, int use_clamp, float lo, float hi,
                     const float* noise, uint64_t seed, int64_t* t_model, int64_t* t_index, float* model_out,
                     float* noise_buf, int B, void* stream);
+
+/* The whole ddim_sample_loop (gaussian_diffusion.py:594-674, the sampler playground.py:49-56 calls), same contract as
+ * gpt_sample_loop with gpt_ddim_step as the update.  eta == 0: deterministic, noise / noise_buf may be NULL. */
+int gpt_ddim_sample_loop(const gpt_model_t* m, const gpt_workspace_t* ws, float* x, const void* loss_target,
+                         const void* loss_prev, int loss_is_f64, const float* x_prev, const float* coef,
+                         const float* alphas_cumprod, float eta, const int64_t* host_timestep_map, int n_steps,
+                         int first_step, int last_step, int predict_xstart, int use_clamp, float lo, float hi,
+                         const float* noise, uint64_t seed, int64_t* t_model, int64_t* t_index, float* model_out,
+                         float* noise_buf, int B, void* stream);
 
 /* Quality metric of sampled MNIST-MLP parameter vectors, all B nets at once (replaces moduleify + the per-net loop
  * of batch_test_fn, Gpt/vis.py:398-413, 539-570, around test_epoch, data_gen/train_mnist.py:324-332).

@@ -117,6 +117,39 @@ def p_sample_loop(tb, model_fn, start, step_noise, predict_xstart=True, clip=Fal
     return x
 
 
+def _sqrt32(x):
+    """Correctly rounded fp32 square root (numpy's is on every host; torch's vectorised CPU sqrt was seen 1 ulp off on
+    the GPU box's host CPU, which matters only for a bit-exact check of the per-row scalars)."""
+    return torch.from_numpy(np.sqrt(x.numpy().astype(np.float32)))
+
+
+def ddim_step(tb, model_out, x_t, t, noise, eta=0.0, predict_xstart=True, clip=False, lo=None, hi=None):
+    """ddim_sample (gaussian_diffusion.py:507-552), fp32 op by op."""
+    x0 = model_out if predict_xstart else xstart_from_eps(tb, x_t, t, model_out)
+    if lo is not None:
+        x0 = x0.clamp(lo, hi)
+    if clip:
+        x0 = x0.clamp(-1, 1)
+    eps = (_take(tb.sqrt_recip_alphas_cumprod, t) * x_t - x0) / _take(tb.sqrt_recipm1_alphas_cumprod, t)   # :335-338
+    ab, abp = _take(tb.alphas_cumprod, t), _take(tb.alphas_cumprod_prev, t)
+    sigma = eta * _sqrt32((1 - abp) / (1 - ab)) * _sqrt32(1 - ab / abp)
+    mean = x0 * _sqrt32(abp) + _sqrt32(1 - abp - sigma ** 2) * eps
+    mask = (t != 0).float()[:, None]
+    return mean + mask * sigma * noise, x0
+
+
+def ddim_sample_loop(tb, model_fn, start, step_noise, eta=0.0, predict_xstart=True, clip=False):
+    """ddim_sample_loop_progressive (gaussian_diffusion.py:630-674) with injected noise."""
+    x = start
+    B = x.shape[0]
+    tmap = torch.tensor(tb.timestep_map)
+    for i in reversed(range(tb.T)):
+        t = torch.full((B,), i, dtype=torch.long)
+        out = model_fn(x, tmap[t])
+        x, _ = ddim_step(tb, out, x, t, step_noise(i), eta, predict_xstart, clip)
+    return x
+
+
 def training_mse(tb, model_fn, x_start, t, noise, predict_xstart=True):
     """training_losses MSE branch (gaussian_diffusion.py:721-725, 740-741, 765-777)."""
     x_t = q_sample(tb, x_start, t, noise)

@@ -248,6 +248,61 @@ def test_p_sample_loop_golden(golden, case, resp, tag, px, clip):
         assert torch.isfinite(outs[-1]["sample"]).all()
 
 
+@pytest.mark.parametrize("case,resp,tag,eta,px,clip", [
+    ("mnist_small", "ddim25", "ddim25_eta0", 0.0, True, False), ("mnist_small", "50", "r50_eta05", 0.5, True, False),
+    ("cifar_small", "ddim25", "ddim25_eta1_eps_clip", 1.0, False, True)])
+def test_ddim_sample_loop_golden(golden, case, resp, tag, eta, px, clip):
+    """ddim_sample_loop: whole loop in one host call against the reference's end point, and the
+    per-step path (fused DDIM kernel per step) against the fused loop."""
+    g = golden(f"g11_ddim_{case}_{tag}")
+    m, plan, sd = build(case, "fp32")
+    m.predict_xstart = px
+    diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=px, noise_schedule="linear", steps=1000,
+                                    timestep_respacing=resp)
+    n = diff.num_timesteps
+    assert n == int(g["num_steps"])
+    B = 3
+    _, _, lt, lp, xp = make_inputs(case, B=B, seed=31)
+    noise = torch.stack([step_noise(1234, i, B, plan.D) for i in range(n)])
+    kw = dict(loss_target=lt.to(DEV), loss_prev=lp.to(DEV), x_prev=xp.to(DEV))
+    start = step_noise(1234, -1, B, plan.D).to(DEV)
+    got = diff.ddim_sample_loop(m, (B, plan.D), noise=start, clip_denoised=clip, model_kwargs=kw, device="cuda", eta=eta,
+                                step_noise=noise)
+    ref = g["sample_at_0"]
+    assert np.abs(got.cpu().numpy() - ref).max() / np.abs(ref).max() < 1e-3
+    x = start.clone()
+    t = torch.empty(B, dtype=torch.long, device=DEV)
+    with torch.no_grad():
+        for i in reversed(range(n)):
+            t.fill_(i)
+            out = diff.ddim_sample(m, x, t, clip_denoised=clip, model_kwargs=kw, eta=eta, noise=noise[i].to(DEV))
+            if i == n - 1:
+                r0 = g[f"xstart_at_{i}"]
+                assert np.abs(out["pred_xstart"].cpu().numpy() - r0).max() / np.abs(r0).max() < 1e-3
+            x = out["sample"]
+    assert torch.equal(x, got)                              # same kernels, same order: bit-identical
+
+
+def test_ddim_step_bit_exact():
+    """The fused DDIM update against the oracle's fp32 op-by-op restatement on the same inputs: bit-exact."""
+    from oracle import diffusion as odf
+    B, D = 5, 7960
+    g = torch.Generator().manual_seed(77)
+    mo, xt, nz = torch.randn(B, D, generator=g), torch.randn(B, D, generator=g), torch.randn(B, D, generator=g)
+    t = torch.tensor([0, 1, 17, 500, 999])
+    diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
+    tb = odf.Tables(1000)
+    mod, xtd, nzd, td = mo.to(DEV), xt.to(DEV), nz.to(DEV), t.to(DEV)
+    for eta, px, clamp in ((0.0, True, None), (0.5, True, (-0.7, 0.7)), (1.0, False, None)):
+        out, x0 = torch.empty(B, D, device=DEV), torch.empty(B, D, device=DEV)
+        lo, hi = clamp if clamp else (0.0, 0.0)
+        L.check(L.lib().gpt_ddim_step(L.ptr(mod), L.ptr(xtd), L.ptr(nzd), L.ptr(td),
+                                      L.ptr(diff.coef_table(DEV)), L.ptr(diff._ac_table(DEV)), int(px), int(clamp is not None),
+                                      lo, hi, eta, L.ptr(out), L.ptr(x0), B, D, L.stream()), "ddim")
+        ref, ref0 = odf.ddim_step(tb, mo, xt, t, nz, eta, px, False, *(clamp if clamp else (None, None)))
+        assert torch.equal(x0.cpu(), ref0) and torch.equal(out.cpu(), ref), (eta, px, clamp)
+
+
 def test_p_sample_loop_philox_statistics():
     """Throughput mode (in-kernel Philox noise): repeatable for a seed, and N(0,1) to sampling error."""
     n = 1 << 20

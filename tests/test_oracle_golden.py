@@ -117,6 +117,24 @@ def test_g7_sampling(golden, case, resp, tag, px, clip):
     np.testing.assert_allclose(final.numpy(), g["sample_at_0"], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("case,resp,tag,eta,px,clip", [
+    ("mnist_small", "ddim25", "ddim25_eta0", 0.0, True, False), ("mnist_small", "50", "r50_eta05", 0.5, True, False),
+    ("cifar_small", "ddim25", "ddim25_eta1_eps_clip", 1.0, False, True)])
+def test_g11_ddim(golden, case, resp, tag, eta, px, clip):
+    """ddim_sample_loop against the reference's trajectory, injected noise."""
+    g = golden(f"g11_ddim_{case}_{tag}")
+    plan = plan_of(case, px)
+    sd = od.random_state_dict(plan, seed=0)
+    tb = odf.Tables(1000, resp)
+    assert tb.T == int(g["num_steps"]) and float(g["eta"]) == eta
+    B = 3
+    _, _, lt, lp, xp = make_inputs(case, B=B, seed=31)
+    with torch.no_grad():
+        fn = lambda x, tt: od.forward(sd, plan, x, tt, lt, lp, xp)
+        final = odf.ddim_sample_loop(tb, fn, step_noise(1234, -1, B, plan.D), lambda i: step_noise(1234, i, B, plan.D), eta, px, clip)
+    np.testing.assert_allclose(final.numpy(), g["sample_at_0"], rtol=1e-4, atol=1e-4)
+
+
 def test_g8_permute(golden):
     g = golden("g8_permute")
     for seed in range(16):

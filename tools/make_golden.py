@@ -220,6 +220,36 @@ def g7_sampling(case, respacing, tag, predict_xstart=True, clip=False):
     save(f"g7_sampling_{case}_{tag}", num_steps=d.num_timesteps, **traj)
 
 
+# ------------------------------------------------------------------ G11: ddim_sample_loop with injected noise (row f2)
+def g11_ddim(case, respacing, tag, eta, predict_xstart=True, clip=False):
+    m, plan, sd = ref_model(case)
+    d = create_diffusion(learn_sigma=False, predict_xstart=predict_xstart, noise_schedule="linear", steps=1000,
+                         timestep_respacing=respacing)
+    B = 3
+    _, _, lt, lp, xp = make_inputs(case, B=B, seed=31)
+    start = step_noise(1234, -1, B, plan.D)
+    order = iter(reversed(range(d.num_timesteps)))
+    real = ref_gd.th.randn_like
+
+    def fake_randn_like(x):
+        return step_noise(1234, next(order), B, plan.D)
+
+    traj = {}
+    ref_gd.th.randn_like = fake_randn_like
+    try:
+        i = d.num_timesteps
+        for out in d.ddim_sample_loop_progressive(
+                m, (B, plan.D), noise=start, clip_denoised=clip,
+                model_kwargs=dict(loss_target=lt, loss_prev=lp, x_prev=xp), device="cpu", eta=eta):
+            i -= 1
+            if i in (d.num_timesteps - 1, d.num_timesteps // 2, 1, 0):
+                traj[f"sample_at_{i}"] = out["sample"].numpy()
+                traj[f"xstart_at_{i}"] = out["pred_xstart"].numpy()
+    finally:
+        ref_gd.th.randn_like = real
+    save(f"g11_ddim_{case}_{tag}", num_steps=d.num_timesteps, eta=eta, **traj)
+
+
 # ------------------------------------------------------------------ G8: permutation index maps
 def g8_permute():
     import data_gen.train_mnist as tm
@@ -295,6 +325,11 @@ def g10_mlp_eval():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g11":          # only the DDIM fixtures (added after G1-G10)
+        g11_ddim("mnist_small", "ddim25", "ddim25_eta0", 0.0)
+        g11_ddim("mnist_small", "50", "r50_eta05", 0.5)
+        g11_ddim("cifar_small", "ddim25", "ddim25_eta1_eps_clip", 1.0, predict_xstart=False, clip=True)
+        sys.exit(0)
     g1_splits()
     g2_freq()
     for case in ("mnist_small", "cifar_small"):
@@ -311,3 +346,6 @@ if __name__ == "__main__":
     g8_permute()
     g9_trainstep("mnist_small")
     g10_mlp_eval()
+    g11_ddim("mnist_small", "ddim25", "ddim25_eta0", 0.0)
+    g11_ddim("mnist_small", "50", "r50_eta05", 0.5)
+    g11_ddim("cifar_small", "ddim25", "ddim25_eta1_eps_clip", 1.0, predict_xstart=False, clip=True)
