@@ -41,7 +41,7 @@ PEAK = {"bf16": 2500.0, "fp32": 157.3}          # dense MFMA TFLOP/s, /opt/skill
 def flops_per_forward(case):
     """Algorithmic FLOPs per sample per denoiser forward."""
     c = CASES[case]
-    d, Lr, T, D = c["n_embd"], c["n_layer"], 26, sum(c["parameter_sizes"])
+    d, Lr, T, D = c["n_embd"], c["n_layer"], 26, sum(c["parameter_sizes"])   # T: both real token plans have 26 tokens
     return 2 * T * Lr * 12 * d * d + 4 * Lr * T * T * d + 2 * d * (2 * D + 4 * 257) + 2 * d * D
 
 
@@ -140,7 +140,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--mode", default="sample", choices=["sample", "train"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--case", default="mnist", choices=["mnist", "cifar"])
+    ap.add_argument("--case", default="mnist", choices=["mnist", "cifar", "cifar_big"])
+    ap.add_argument("--augment", action="store_true",
+                    help="train mode: on-device permutation augmentation of every checkpoint pair (configs[4])")
     ap.add_argument("--batch", type=int, default=None, help="rows per GPU (default 320 sample / 128 train)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the short training-step measurement ('train' object)")

@@ -216,16 +216,30 @@ def bench_train(args, device, world, rank):
     diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
     sampler = gpt_amd.UniformSampler(diff)
     np.random.seed(world + rank)               # Gpt/utils.py:73-75 with rng_seed = 1
-    ts = TrainStep(model, diff, lr=4e-4, wd=0.1, betas=(0.9, 0.999), grad_clip=0.75, ema_decay=0.9999)
+    mnist = case.startswith("mnist")
+    clip = 0.75 if mnist else 0.1              # configs/train/mnist_loss.yaml / cifar10_error.yaml: train.grad_clip
+    cfg_name = "configs/train/mnist_loss.yaml" if mnist else "configs/train/cifar10_error.yaml"
+    if case == "cifar_big":
+        c = CASES[case]
+        cfg_name += f" with a scaled-up transformer (n_embd {c['n_embd']}, {c['n_head']} heads, {c['n_layer']} layers)"
+    ts = TrainStep(model, diff, lr=4e-4, wd=0.1, betas=(0.9, 0.999), grad_clip=clip, ema_decay=0.9999)
     batches = [synthetic_pairs(case, B, device, seed=1000 * rank + i) for i in range(4)]
     iters_per_epoch = 1000
+    augment = getattr(args, "augment", False)
+    if augment:
+        from . import permute
+        arch = permute.MLP_ARCH if case.startswith("mnist") else permute.CNN_ARCH
 
     def run(n, first):
         last = None
         for i in range(first, first + n):
             ts.set_lr(lr_at(4e-4, 25000, 5, 0.0, i / iters_per_epoch))
             t, wts = sampler.sample(B, device)
-            last = ts.step(*batches[i % len(batches)], t, weights=wts)
+            w_t, w_t1, l_t, l_t1 = batches[i % len(batches)]
+            if augment:     # one function-preserving permutation per pair, on the GPU (Gpt/data/augment.py:25-75)
+                seeds = range((i * world + rank) * B, (i * world + rank + 1) * B)
+                w_t, w_t1 = permute.random_permute_batch([w_t, w_t1], arch, seeds)
+            last = ts.step(w_t, w_t1, l_t, l_t1, t, weights=wts)
         return last
 
     run(args.warmup, 0)
@@ -246,9 +260,10 @@ def bench_train(args, device, world, rank):
         "metric": "train iters/sec (DDP)", "value": 1e3 / ms, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"configs/train/{case}_loss.yaml step on synthetic checkpoint pairs: q_sample + denoiser "
-                               f"forward/backward + grad all-reduce + clip 0.75 + AdamW(4e-4, wd 0.1) + EMA 0.9999; "
-                               f"B={B} pairs per GPU (global {B * world})",
+        "config": {"workload": f"{cfg_name} step on synthetic checkpoint pairs: q_sample + denoiser "
+                               f"forward/backward + grad all-reduce + clip {clip} + AdamW(4e-4, wd 0.1) + EMA 0.9999; "
+                               f"B={B} pairs per GPU (global {B * world})"
+                               + ("; on-device permutation augmentation of every pair" if augment else ""),
                    "batch_per_gpu": B, "global_batch": B * world},
         "samples_per_s": B * world * 1e3 / ms, "model_tflops_per_gpu": flops / (ms * 1e-3) / 1e12,
         "final_loss": loss,

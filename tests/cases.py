@@ -24,6 +24,10 @@ CASES = {
     "cifar": dict(parameter_sizes=CIFAR_SIZES, parameter_names=CIFAR_NAMES, n_embd=2048, n_head=16,
                   n_layer=12, chunk_size=576, split_policy="chunk_within_layer", loss_lo=40.0, loss_hi=90.0,
                   loss_target=35.0, w_std=0.538),
+    # BASELINE.json configs[4]: CIFAR shapes with a scaled-up transformer (the reference defines none)
+    "cifar_big": dict(parameter_sizes=CIFAR_SIZES, parameter_names=CIFAR_NAMES, n_embd=3072, n_head=24,
+                      n_layer=24, chunk_size=576, split_policy="chunk_within_layer", loss_lo=40.0, loss_hi=90.0,
+                      loss_target=35.0, w_std=0.538),
 }
 
 
