@@ -51,9 +51,18 @@ __device__ __forceinline__ float erf_fast(float x) {
   const float erf_abs = fmaf(-poly, __builtin_amdgcn_exp2f(-zp * zp), 1.0f);
   return copysignf(erf_abs, x);
 }
+// bf16 forward GELU: x * sigmoid(a x + b x^3 + c x^5), coefficients fitted (minimax over [-8, 8]) to the EXACT erf GELU of
+// nn.GELU(): |error| <= 2.6e-5 absolute, i.e. below half a bf16 ulp of the result wherever |gelu| >= 0.013 and below the
+// bf16 rounding of the activations it is summed with elsewhere.  11 VALU issue slots per element against 16 for the erf
+// form above (the GELU epilogue is VALU-bound: 128 elements per lane after every tile).  fp32 mode: libm erff.
 __device__ __forceinline__ float gelu_fast(float x) {
-  const float hx = 0.5f * x;
-  return fmaf(hx, erf_fast(x), hx);
+  // -log2(e) * (a, b, c): sigmoid(p) = 1 / (1 + exp2(-log2(e) p))
+  constexpr float A = -1.5950157686361435f * 1.4426950408889634f, B = -0.07401129203229191f * 1.4426950408889634f,
+                  Cc = 0.000703033580348536f * 1.4426950408889634f;
+  const float xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);   // the fit's range: beyond it sigmoid is 0 / 1 to fp32 anyway
+  const float x2 = xc * xc;
+  const float q = xc * fmaf(x2, fmaf(x2, Cc, B), A);
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(q));
 }
 // d/dx gelu(x) = Phi(x) + x phi(x), same approximation (bf16 training mode)
 __device__ __forceinline__ float gelu_fast_grad(float x) {

@@ -84,6 +84,24 @@ def test_gemm_epilogues(dtype, tol, M, N, K):
     assert rel_err(out.float().cpu(), torch.nn.functional.gelu(ref)) < tol
 
 
+def test_gemm_gelu_bf16_range():
+    """bf16 GELU epilogue (x * sigmoid(fitted odd polynomial)) against the exact erf GELU over [-30, 30], outliers included:
+    error <= one bf16 rounding of the result + 2.6e-5 (the fit's bound, gemm_common.h)."""
+    M, N, K = 4096, 64, 64
+    x = torch.cat([torch.linspace(-30, 30, M - 6), torch.tensor([-1e4, 1e4, -11.5, 11.5, 0.0, -0.0])]).bfloat16()
+    A = torch.zeros(M, K, dtype=torch.bfloat16)
+    A[:, 0] = x
+    W = torch.zeros(N, K, dtype=torch.bfloat16)
+    W[:, 0] = 1.0
+    Ad, Wd = A.to(DEV), W.to(DEV)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    L.check(L.lib().gpt_gemm_nt(L.BF16, L.ptr(Ad), K, L.ptr(Wd), K, None, L.ptr(out), N, None, 0, M, N, K, L.EPI_GELU,
+                                L.stream()), "gemm")
+    ref = torch.nn.functional.gelu(x.double())[:, None].expand(M, N)
+    err = (out.cpu().double() - ref).abs()
+    assert bool((err <= ref.abs() * 2.0 ** -8 + 2.6e-5).all()), float(err.max())
+
+
 def test_gemm_rejects_bad_shapes():
     a = torch.zeros(8, 40, device=DEV)
     st = L.lib().gpt_gemm_nt(L.F32, L.ptr(a), 40, L.ptr(a), 40, None, L.ptr(a), 8, None, 0, 8, 8, 40, 0, L.stream())

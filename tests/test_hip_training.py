@@ -291,7 +291,7 @@ def test_two_rank_step_equals_full_batch(tmp_path):
         assert float((p.detach().cpu() - got[k]).abs().max()) < 5e-5 * max(1.0, float(got[k].abs().max())), k
 
 
-@pytest.mark.parametrize("I,J,R", [(256, 256, 64), (512, 768, 832), (1536, 256, 3328)])
+@pytest.mark.parametrize("I,J,R", [(256, 256, 64), (512, 768, 832), (1536, 256, 3328), (256, 512, 8256)])   # last: 16 row spans, ragged
 @pytest.mark.parametrize("accumulate", [0, 1])
 def test_gemm_tn_matches_torch(I, J, R, accumulate):
     """C (+)= P^T Q with both bf16 operands read as stored (transposing LDS reads) against an fp64 product."""
