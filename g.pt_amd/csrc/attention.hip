@@ -9,11 +9,20 @@
 //                        reduction, no LDS);
 //   O^T = V^T . P^T      the softmaxed accumulator IS the B operand of the second MFMA (a product that sums
 //                        over the accumulator's row index needs no lane movement); V^T fragments are read
-//                        with the matching key order.
+//                        with the matching key order.  bf16: the V tile is staged in LDS by coalesced 16-byte loads
+//                        (rows >= T zero-filled) and its transposed fragments (8 keys of one head-dim per lane) come
+//                        from ds_read_b64_tr_b16, 12 LDS reads instead of 48 two-byte global loads per lane.
 // fp32: v_mfma_f32_32x32x2_f32 (exact).  bf16: v_mfma_f32_32x32x16_bf16, P rounded to bf16 once.
 #include "common.h"
 
 namespace {
+
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s* lds_v4s_ptr;
+// LDS row pitch of the staged V tile: the 4 rows x 16 columns blocks of the transposing read land on 64 distinct banks
+// with 192-byte rows (48 banks apart) and with 320-byte rows (16 banks apart), not with 128- or 256-byte rows
+template <int HD>
+constexpr int v_pitch = HD == 128 ? 320 : 192;
 
 __device__ __forceinline__ int key_of(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
@@ -32,6 +41,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
   const T* vb = qb + 2 * d;
   const bool rvalid = r < Ttok;
   const int64_t roff = (int64_t)(rvalid ? r : 0) * ld;
+
+  // bf16: V tile -> registers now (in flight during the score MFMAs), -> LDS after them
+  constexpr int VP = v_pitch<HD>, CPR = HD / 8, NVL = (32 * CPR + 63) / 64;
+  __shared__ __attribute__((aligned(16))) char vsm[sizeof(T) == 2 ? 4 * 32 * VP : 16];
+  char* vt = vsm + (sizeof(T) == 2 ? (threadIdx.x >> 6) * 32 * VP : 0);
+  u32x4 vreg[NVL];
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+      const int c = lane + 64 * i, row = c / CPR, col = c - row * CPR;
+      vreg[i] = u32x4{0, 0, 0, 0};
+      if (row < Ttok) vreg[i] = *reinterpret_cast<const u32x4*>(vb + (int64_t)row * ld + col * 8);
+    }
+  }
 
   f32x16 S;
 #pragma unroll
@@ -92,17 +115,28 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) p[s][j] = (short)f32_to_bf16(S[8 * s + j]);
+      for (int j = 0; j < 8; j += 2) {
+        const uint32_t pk = pack_bf16x2(S[8 * s + j], S[8 * s + j + 1]);
+        p[s][j] = (short)(pk & 0xffffu);
+        p[s][j + 1] = (short)(pk >> 16);
+      }
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+      const int c = lane + 64 * i, row = c / CPR, col = c - row * CPR;
+      if (c < 32 * CPR) *reinterpret_cast<u32x4*>(vt + row * VP + col * 16) = vreg[i];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own writes only: the LDS serves one wave's instructions in order
+    // transposing read: in every 16-lane group gq, lane 4 q + pp supplies row (key) q, columns 4 pp .. 4 pp + 3 of a
+    // 4 x 16 block and lane i receives column i of its four rows: keys 16 s + 8 u + 4 hh + q, head-dims 32 t + 16 (gq & 1) + i
+    const int gq = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+    const char* tbase = vt + (4 * (gq >> 1) + tq) * VP + (16 * (gq & 1) + 4 * tp) * 2;
 #pragma unroll
     for (int t = 0; t < ND; ++t) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        bf16x8 v;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int key = key_of(8 * s + j, hh);
-          v[j] = key < Ttok ? (short)vb[(int64_t)key * ld + t * 32 + r] : (short)0;
-        }
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(tbase + (16 * s) * VP + t * 64));
+        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(tbase + (16 * s + 8) * VP + t * 64));
+        const bf16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v, p[s], O[t], 0, 0, 0);
       }
     }
