@@ -178,6 +178,25 @@ def test_forward_golden_fp32(golden, case):
     assert rel_err(hf, g["ln_f"]) < 2e-4
 
 
+@pytest.mark.parametrize("case", ["mnist", "cifar"])
+def test_forward_full_size_vs_oracle(case):
+    """north_star check 1 at the pretrained shapes (d = 1536 / 2048, 12 layers): fp32 denoiser output within 1e-3 of the
+    oracle, relative to the network's own contribution; B = 64 rows so that the 256 x 256 GEMM kernel, its edge tiles and
+    the ring kernels all take part.  bf16 on the same inputs within bf16 rounding of fp32."""
+    m, plan, sd = build(case, "fp32", seed=2)
+    cpu = make_inputs(case, B=64, seed=13)
+    dev = tuple(v.to(DEV) for v in cpu)
+    with torch.no_grad():
+        out = m(dev[0], dev[1], dev[2], loss_prev=dev[3], x_prev=dev[4]).cpu()
+        ref = od.forward(sd, plan, *cpu)
+    scale = float((ref - cpu[4]).abs().max())
+    assert float((out - ref).abs().max()) / scale < 1e-3
+    m.set_compute_dtype("bf16")
+    with torch.no_grad():
+        out16 = m(dev[0], dev[1], dev[2], loss_prev=dev[3], x_prev=dev[4]).cpu()
+    assert float((out16 - ref).abs().max()) / scale < 3e-2
+
+
 @pytest.mark.parametrize("case", ["mnist_small", "cifar_small"])
 def test_forward_oracle_bf16(case):
     m, plan, sd = build(case, "bf16", seed=3)
