@@ -66,6 +66,8 @@ _PROTOS = {
     "gpt_scalar_tokens": ([vp, vp, vp, i32, vp, i32, i32, vp, i32, vp], i32),
     "gpt_encode_tokens": ([i32, i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64), C.POINTER(i32),
                            vp, i32, i32, vp], i32),
+    "gpt_encode_tokens_subset": ([i32, i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64), C.POINTER(i32),
+                                  C.POINTER(i32), i32, vp, i32, i32, vp], i32),
     "gpt_decode_tokens": ([i32, i32, vp, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), vp, vp, i32, i32, i32,
                            vp], i32),
     "gpt_q_sample": ([vp, vp, vp, vp, vp, i32, i32, vp], i32),

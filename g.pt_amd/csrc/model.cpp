@@ -28,9 +28,11 @@ static int validate(const gpt_model_t* m, const gpt_workspace_t* ws, int B, cons
   return 0;
 }
 
-extern "C" int gpt_denoiser_forward(const gpt_model_t* m, const gpt_workspace_t* ws, const float* x, const int64_t* t,
-                                    const void* loss_target, const void* loss_prev, int loss_is_f64,
-                                    const float* x_prev, float* out, int B, void* stream) {
+// enc_cached != 0: the encoder output of the tokens that do not depend on x or t (x_prev, the loss scalars) is already in
+// ws->enc from an earlier call with the same x_prev / losses (the sampling loops): only the other tokens are encoded.
+static int denoiser_forward(const gpt_model_t* m, const gpt_workspace_t* ws, const float* x, const int64_t* t,
+                            const void* loss_target, const void* loss_prev, int loss_is_f64, const float* x_prev, float* out,
+                            int B, int enc_cached, void* stream) {
   CHECK(validate(m, ws, B, "gpt_denoiser_forward"));
   GPT_REQUIRE(x && t && loss_target && loss_prev && x_prev && out, "gpt_denoiser_forward: null operand");
   const int d = m->d, T = m->T, M = B * T, L = m->n_layer, dt = m->dtype;
@@ -42,16 +44,25 @@ extern "C" int gpt_denoiser_forward(const gpt_model_t* m, const gpt_workspace_t*
   CHECK(gpt_scalar_tokens(t, loss_target, loss_prev, loss_is_f64, m->freqs, m->nfreq, m->n_scalar, ws->scal, B, stream));
 
   const float* src[GPT_MAX_TOKENS];
-  int64_t src_ld[GPT_MAX_TOKENS];
+  const void* wsel[GPT_MAX_TOKENS];
+  int64_t src_ld[GPT_MAX_TOKENS], w_ld[GPT_MAX_TOKENS];
+  int ksel[GPT_MAX_TOKENS], slot[GPT_MAX_TOKENS];
+  int n_sel = 0;
   for (int i = 0; i < m->T; ++i) {
+    const float* sp;
+    int64_t sld;
+    bool varies;                       // with x or t
     switch (m->enc_src[i]) {
-      case GPT_SRC_X: src[i] = x + m->enc_off[i]; src_ld[i] = m->D; break;
-      case GPT_SRC_XPREV: src[i] = x_prev + m->enc_off[i]; src_ld[i] = m->D; break;
-      case GPT_SRC_SCALAR: src[i] = ws->scal + m->enc_off[i]; src_ld[i] = (int64_t)m->n_scalar * W; break;
+      case GPT_SRC_X: sp = x + m->enc_off[i]; sld = m->D; varies = true; break;
+      case GPT_SRC_XPREV: sp = x_prev + m->enc_off[i]; sld = m->D; varies = false; break;
+      case GPT_SRC_SCALAR: sp = ws->scal + m->enc_off[i]; sld = (int64_t)m->n_scalar * W; varies = m->enc_off[i] == 0; break;
       default: gpt_set_error("gpt_denoiser_forward: token %d: bad source kind %d", i, m->enc_src[i]); return -1;
     }
+    if (enc_cached && !varies) continue;
+    src[n_sel] = sp; src_ld[n_sel] = sld; wsel[n_sel] = m->enc_w[i]; w_ld[n_sel] = m->enc_w_ld[i]; ksel[n_sel] = m->enc_k[i];
+    slot[n_sel++] = i;
   }
-  CHECK(gpt_encode_tokens(dt, T, src, src_ld, m->enc_w, m->enc_w_ld, m->enc_k, ws->enc, B, d, stream));
+  CHECK(gpt_encode_tokens_subset(dt, n_sel, src, src_ld, wsel, w_ld, ksel, slot, T, ws->enc, B, d, stream));
 
   auto xbuf = [&](int idx) { return ws->x + (keep ? (size_t)idx * Mmax * d : 0); };
   auto lay = [&](void* base, int l, size_t width) {
@@ -85,9 +96,17 @@ extern "C" int gpt_denoiser_forward(const gpt_model_t* m, const gpt_workspace_t*
     }
     CHECK(gpt_gemm_nt(dt, act, 4 * d, ly.w2, 4 * d, ly.b2, xout, d, keep ? xmid : nullptr, d, M, d, 4 * d, GPT_EPI_RESADD, stream));
   }
+  // (Pruning the rows of the tokens the decoder does not read after the last block's attention was built and measured in
+  // r01: no gain at B = 320 - the compacted 3520-row GEMMs fall to the slower small-problem kernels.)
   CHECK(gpt_layernorm(xbuf(2 * L), m->ln_f_w, m->ln_f_b, nullptr, 0, ws->hf, dt, stat(2 * L + 1, 0), stat(2 * L + 1, 1), M, d, 1e-5f, stream));
   CHECK(gpt_decode_tokens(dt, m->n_out_tok, ws->hf, T, m->dec_w, m->dec_n, m->dec_off, x_prev, out, B, d, m->D, stream));
   return 0;
+}
+
+extern "C" int gpt_denoiser_forward(const gpt_model_t* m, const gpt_workspace_t* ws, const float* x, const int64_t* t,
+                                    const void* loss_target, const void* loss_prev, int loss_is_f64,
+                                    const float* x_prev, float* out, int B, void* stream) {
+  return denoiser_forward(m, ws, x, t, loss_target, loss_prev, loss_is_f64, x_prev, out, B, 0, stream);
 }
 
 // ddim: 0 = ancestral DDPM step (gpt_posterior_step), 1 = DDIM step with `eta` (gpt_ddim_step, needs alphas_cumprod)
@@ -109,7 +128,8 @@ static int sample_loop(const char* who, int ddim, float eta, const float* alphas
   for (int i = first_step; i >= last_step; --i) {
     CHECK(gpt_fill_i64(t_index, B, i, stream));
     CHECK(gpt_fill_i64(t_model, B, host_timestep_map[i], stream));
-    CHECK(gpt_denoiser_forward(m, ws, x, t_model, loss_target, loss_prev, loss_is_f64, x_prev, model_out, B, stream));
+    // x_prev and the losses are the loop's constants: their tokens are encoded in the first step only
+    CHECK(denoiser_forward(m, ws, x, t_model, loss_target, loss_prev, loss_is_f64, x_prev, model_out, B, i != first_step, stream));
     const float* nz = nullptr;
     if (need_noise) {
       nz = noise ? noise + (int64_t)i * BD : noise_buf;

@@ -63,6 +63,7 @@ struct EncTok {
   const void* w;      // T [d, w_ld], zero padded to a multiple of KC
   int64_t src_ld, w_ld;
   int k;
+  int slot;           // output token index
 };
 struct EncArgs {
   EncTok tok[MAX_TOK];
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) void encode_kernel(EncArgs g) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int b = b0 + wr * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-      if (b < g.B) g.out[((int64_t)b * g.n_tok + blockIdx.z) * g.d + n] = acc[j][e];
+      if (b < g.B) g.out[((int64_t)b * g.n_tok + tk.slot) * g.d + n] = acc[j][e];
     }
   }
 }
@@ -277,27 +278,36 @@ extern "C" int gpt_scalar_tokens(const int64_t* t, const void* loss_target, cons
   return gpt_launch_status("gpt_scalar_tokens");
 }
 
-extern "C" int gpt_encode_tokens(int dtype, int n_tok, const float* const* host_src, const int64_t* host_src_ld,
-                                 const void* const* host_w, const int64_t* host_w_ld, const int* host_k, float* out,
-                                 int B, int d, void* stream) {
+extern "C" int gpt_encode_tokens_subset(int dtype, int n_sel, const float* const* host_src, const int64_t* host_src_ld,
+                                        const void* const* host_w, const int64_t* host_w_ld, const int* host_k,
+                                        const int* host_slot, int n_tok, float* out, int B, int d, void* stream) {
   GPT_REQUIRE(dtype == GPT_F32 || dtype == GPT_BF16, "gpt_encode_tokens: bad dtype %d", dtype);
-  GPT_REQUIRE(n_tok > 0 && n_tok <= MAX_TOK, "gpt_encode_tokens: n_tok=%d out of range (max %d)", n_tok, MAX_TOK);
+  GPT_REQUIRE(n_tok > 0 && n_tok <= MAX_TOK && n_sel > 0 && n_sel <= n_tok, "gpt_encode_tokens: n_tok=%d / n_sel=%d out of range (max %d)",
+              n_tok, n_sel, MAX_TOK);
   GPT_REQUIRE(B > 0 && d > 0 && d % 8 == 0 && out, "gpt_encode_tokens: bad sizes");
   const int esz = dtype == GPT_BF16 ? 2 : 4;
   EncArgs g;
-  for (int i = 0; i < n_tok; ++i) {
+  for (int i = 0; i < n_sel; ++i) {
     GPT_REQUIRE(host_src[i] && host_w[i] && host_k[i] > 0, "gpt_encode_tokens: token %d: null/empty", i);
     const int kp = (host_k[i] + KC - 1) / KC * KC;
     GPT_REQUIRE(host_w_ld[i] >= kp && (host_w_ld[i] * esz) % 16 == 0 && ((uintptr_t)host_w[i] % 16) == 0,
                 "gpt_encode_tokens: token %d: weight rows must be zero-padded to a multiple of %d and 16-byte aligned", i, KC);
     GPT_REQUIRE(host_src_ld[i] >= host_k[i], "gpt_encode_tokens: token %d: src_ld < k", i);
-    g.tok[i] = EncTok{host_src[i], host_w[i], host_src_ld[i], host_w_ld[i], host_k[i]};
+    const int slot = host_slot ? host_slot[i] : i;
+    GPT_REQUIRE(slot >= 0 && slot < n_tok, "gpt_encode_tokens: token %d: output slot %d out of range", i, slot);
+    g.tok[i] = EncTok{host_src[i], host_w[i], host_src_ld[i], host_w_ld[i], host_k[i], slot};
   }
   g.out = out; g.n_tok = n_tok; g.B = B; g.d = d;
-  const dim3 grid((d + TN - 1) / TN, (B + TB - 1) / TB, n_tok), block(256);
+  const dim3 grid((d + TN - 1) / TN, (B + TB - 1) / TB, n_sel), block(256);
   if (dtype == GPT_BF16) hipLaunchKernelGGL(encode_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, g);
   else hipLaunchKernelGGL(encode_kernel<float>, grid, block, 0, (hipStream_t)stream, g);
   return gpt_launch_status("gpt_encode_tokens");
+}
+
+extern "C" int gpt_encode_tokens(int dtype, int n_tok, const float* const* host_src, const int64_t* host_src_ld,
+                                 const void* const* host_w, const int64_t* host_w_ld, const int* host_k, float* out,
+                                 int B, int d, void* stream) {
+  return gpt_encode_tokens_subset(dtype, n_tok, host_src, host_src_ld, host_w, host_w_ld, host_k, nullptr, n_tok, out, B, d, stream);
 }
 
 extern "C" int gpt_decode_tokens(int dtype, int n_tok, const void* feat, int T, const void* const* host_w,

@@ -90,6 +90,13 @@ int gpt_encode_tokens(int dtype, int n_tok, const float* const* host_src, const 
                       const void* const* host_w, const int64_t* host_w_ld, const int* host_k,
                       float* out, int B, int d, void* stream);
 
+/* The same for n_sel of the n_tok tokens: descriptor i writes out[b, slot[i], :] (slot == NULL: identity).  Inside
+ * p_sample_loop only x and t change from step to step (gaussian_diffusion.py:492-505): the tokens of x_prev and of the
+ * two losses are encoded once per loop. */
+int gpt_encode_tokens_subset(int dtype, int n_sel, const float* const* host_src, const int64_t* host_src_ld,
+                             const void* const* host_w, const int64_t* host_w_ld, const int* host_k,
+                             const int* host_slot, int n_tok, float* out, int B, int d, void* stream);
+
 /* Ragged per-token decoder + global residual: for j < n_tok,
  * out[b, off_j .. off_j+n_j) = feat[b, j, :] . W_j[n_j, d]^T + resid[b, off_j ..].
  * feat: `dtype` [B, T, d]; out/resid: fp32 [B, D] (resid may be NULL).
