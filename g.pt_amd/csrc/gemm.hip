@@ -30,7 +30,7 @@
 
 namespace gemmk {
 GemmProf g_prof;
-int gemm256_bf16(const GemmArgs<bf16_t>& g, int epi, hipStream_t s);  // gemm256.hip
+int gemm256_bf16(const GemmArgs<bf16_t>& g, int epi, int rt, hipStream_t s);  // gemm256.hip; rt = 8 | 7 (256- / 224-row tiles)
 int gemm256_f32(const GemmArgs<float>& g, int epi, hipStream_t s);
 }
 
@@ -236,26 +236,48 @@ int dispatch_ring(const GemmArgs<T>& g, int epi, hipStream_t s);
 // The 256 x 256 kernel runs one workgroup per CU, so a launch costs ceil(tiles / 256) full rounds however empty the
 // last one is (B = 320: 594 tiles -> 3 rounds at 77 %).  When the last round would be poorly filled, the row-tiles
 // that do not fill whole rounds are handed to the 128 x 128 kernel (2 workgroups per CU, a quarter of the work each).
-template <typename T>
-int split_rows(const GemmArgs<T>& g) {
+int n_cus() {
   static const int n_cu = [] {
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
     return n > 0 ? n : 256;
   }();
+  return n_cu;
+}
+
+// cost in units of one full round of 256 x 256 tiles; *m_main = rows given to the 256 x 256 kernel (the rest: ring kernels)
+template <typename T>
+double plan_rows256(const GemmArgs<T>& g, int* m_main) {
   static const bool enabled = [] {
     const char* e = getenv("GPT_GEMM_SPLIT");  // 0 disables (experiments)
     return !e || atoi(e) != 0;
   }();
+  const int n_cu = n_cus();
   const int tn = (g.N + 255) / 256, tm = (g.M + 255) / 256, tiles = tm * tn;
   const int rounds = tiles / n_cu, rem = tiles % n_cu;
-  if (!enabled || rounds == 0 || rem == 0 || rem * 4 > n_cu) return g.M;
+  *m_main = g.M;
+  const double whole = (tiles + n_cu - 1) / n_cu;
+  if (!enabled || rounds == 0 || rem == 0 || rem * 4 > n_cu) return whole;
   const int main_tiles_m = rounds * n_cu / tn;
-  const int m_main = main_tiles_m * 256;
-  if (m_main <= 0 || m_main >= g.M) return g.M;
-  const int tail128 = ((g.M - m_main + 127) / 128) * ((g.N + 127) / 128);
+  const int mm = main_tiles_m * 256;
+  if (mm <= 0 || mm >= g.M) return whole;
+  const int tail128 = ((g.M - mm + 127) / 128) * ((g.N + 127) / 128);
   const double cost_split = rounds + 0.5 * ((tail128 + 2 * n_cu - 1) / (2 * n_cu)) + 0.08;
-  return cost_split < rounds + 1 ? m_main : g.M;
+  if (cost_split < whole) { *m_main = mm; return cost_split; }
+  return whole;
+}
+
+// 224-row tiles (bf16): whole rounds of 7/8 the work each, a little extra for the unused A rows they stage
+template <typename T>
+double cost_rows224(const GemmArgs<T>& g) {
+  static const bool enabled = [] {
+    const char* e = getenv("GPT_GEMM_224");    // 0 disables (experiments)
+    return !e || atoi(e) != 0;
+  }();
+  if (!enabled || sizeof(T) != 2) return 1e30;
+  const int n_cu = n_cus();
+  const int tiles = ((g.M + 223) / 224) * ((g.N + 255) / 256);
+  return ((tiles + n_cu - 1) / n_cu) * 0.875 + 0.02;
 }
 
 template <typename T>
@@ -263,11 +285,16 @@ int dispatch(const GemmArgs<T>& g, int epi, hipStream_t s) {
   const int tiles256 = ((g.M + 255) / 256) * ((g.N + 255) / 256);
   const bool k_ok = g.K % (128 / (int)sizeof(T)) == 0;   // the 256 x 256 kernel moves 128 bytes of K per row and K-tile
   if (k_ok && (tile_mode() == 3 || (tile_mode() == 0 && tiles256 >= 128))) {
-    const int m_main = tile_mode() == 0 ? split_rows(g) : g.M;
+    int m_main = g.M;
+    int rt = 8;
+    if (tile_mode() == 0) {
+      const double c8 = plan_rows256(g, &m_main);
+      if (cost_rows224(g) < c8 - 0.01) { rt = 7; m_main = g.M; }
+    }
     GemmArgs<T> head = g;
     head.M = m_main;
     int rc;
-    if constexpr (sizeof(T) == 2) rc = gemm256_bf16(head, epi, s);
+    if constexpr (sizeof(T) == 2) rc = gemm256_bf16(head, epi, rt, s);
     else rc = gemm256_f32(head, epi, s);
     if (rc != 0 || m_main == g.M) return rc;
     const bool c32 = epi == GPT_EPI_RESADD || epi == GPT_EPI_STORE_F32 || epi == GPT_EPI_ACCUM_F32;

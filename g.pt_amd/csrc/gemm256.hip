@@ -57,8 +57,14 @@ __device__ __forceinline__ u32x4 frag(const char* half, int row, int lc) {
 
 // (A stream-K variant - one workgroup per CU, equal spans of the tile x K-tile space, partial tiles added with float
 // atomics - was built and measured in r01: slower on every shape of this model, proj 70 -> 154 us; removed.)
-template <typename T, int EPI>
+// RT = 16-row MFMA tiles per wave: 8 -> the 256-row block tile; 7 -> a 224-row block tile (bf16 only) for problems whose
+// row count fills the CUs badly in 256-row tiles (M = 8320 = 32.5 x 256: proj / fc2 put 198 tiles on 256 CUs; in 224-row
+// tiles it is 228 tiles of 7/8 the work).  The LDS image and the DMA schedule do not change: A-h1 simply carries 16 unused
+// rows per wave-row (their sources are clamped to valid rows).
+template <typename T, int EPI, int RT>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
+  static_assert(RT == 8 || (RT == 7 && sizeof(T) == 2), "224-row tiles exist for the 16x16x32 bf16 path only");
+  constexpr int BM = 32 * RT, WROWS = 16 * RT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -83,10 +89,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
 #define GPT_GROUP_N 8
 #endif
   constexpr int GROUP_N = GPT_GROUP_N;
-  const int tiles_m = (g.M + 255) / 256;
+  const int tiles_m = (g.M + BM - 1) / BM;
   const int gb = tile / (tiles_m * GROUP_N), grem = tile - gb * (tiles_m * GROUP_N);
   const int gw = min(GROUP_N, tiles_n - gb * GROUP_N);
-  const int m0 = (grem / gw) * 256, n0 = (gb * GROUP_N + grem % gw) * 256;
+  const int m0 = (grem / gw) * BM, n0 = (gb * GROUP_N + grem % gw) * 256;
 
   // per-lane DMA source rows: this wave fills LDS rows [wid*16, wid*16+16) of every half-tile (2 pieces of 8 rows)
   const T* srcA[2][2];  // [half][piece]
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
     const int lc = (lane & 7) ^ ((lr >> 1) & 7);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      int gm = m0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
+      int gm = m0 + (lr >> 6) * WROWS + min(h * 64 + (lr & 63), WROWS - 1);
       gm = gm < g.M ? gm : g.M - 1;
       srcA[h][p] = g.A + (int64_t)gm * g.lda + lc * EPC;
       int gn = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
@@ -114,11 +120,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
   // bf16: 16x16x32 MFMAs, 8 x 4 accumulator tiles of 16 x 16 (the chip holds a higher clock on this shape than on
   // 32x32x16 at the same cycles per FLOP and the same LDS traffic: +4...8 % measured);  fp32: 32x32x2, 4 x 2 tiles of 32 x 32
   constexpr bool M16 = sizeof(T) == 2;
-  f32x4 acc16[M16 ? 8 : 1][M16 ? 4 : 1];
+  f32x4 acc16[M16 ? RT : 1][M16 ? 4 : 1];
   f32x16 acc[M16 ? 1 : 4][M16 ? 1 : 2];
   if constexpr (M16) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   } else {
@@ -150,9 +156,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj)
-            acc16[4 * (i0 >> 1) + i][2 * j + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(bf16x8, a[i >> 1][2 * (i & 1) + kk]), __builtin_bit_cast(bf16x8, b[2 * jj + kk]),
-                acc16[4 * (i0 >> 1) + i][2 * j + jj], 0, 0, 0);
+            if (4 * (i0 >> 1) + i < RT)      // compile time once unrolled (i0 is a literal at every call site)
+              acc16[4 * (i0 >> 1) + i][2 * j + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  __builtin_bit_cast(bf16x8, a[i >> 1][2 * (i & 1) + kk]), __builtin_bit_cast(bf16x8, b[2 * jj + kk]),
+                  acc16[4 * (i0 >> 1) + i][2 * j + jj], 0, 0, 0);
     } else {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
@@ -166,12 +173,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
   };
   // fragment reads of one half-tile: A half = 64 rows of this wave (base row wr * 64), W half = 32 columns (base wc * 32)
   const int l15 = lane & 15, l4 = lane >> 4;
-  auto read_a = [&](u32x4 (&a)[2][4], const char* half) {
+  auto read_a = [&](u32x4 (&a)[2][4], const char* half, int h) {
     if constexpr (M16) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) a[i >> 1][2 * (i & 1) + kk] = frag(half, wr * 64 + i * 16 + l15, 4 * kk + l4);
+        for (int kk = 0; kk < 2; ++kk)
+          if (4 * h + i < RT) a[i >> 1][2 * (i & 1) + kk] = frag(half, wr * 64 + i * 16 + l15, 4 * kk + l4);
     } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
     else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     SEG_BARRIER();
     read_b(b0, buf + 2 * HALF);
-    read_a(a, buf);
+    read_a(a, buf, 0);
     read_b(b1, buf + 3 * HALF);
     if (kt >= 1 && !last) dma(srcA[1], kt + 1, 1);          // A-h1(kt+1): its slot was last read in P1(kt-1)
     SEG_READS_DONE();
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
     if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     SEG_BARRIER();
-    read_a(a, buf + HALF);
+    read_a(a, buf + HALF, 1);
     if (steady) {
       dma(srcA[0], kt + 2, 0);
       dma(srcW[0], kt + 2, 2);
@@ -265,7 +273,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) patch[(ii * 16 + 4 * l4 + e) * PATCH_PITCH + jt * 16 + l15] = acc16[2 * step + ii][jt][e];
+          for (int e = 0; e < 4; ++e)
+            if (2 * step + ii < RT) patch[(ii * 16 + 4 * l4 + e) * PATCH_PITCH + jt * 16 + l15] = acc16[2 * step + ii][jt][e];
     } else {
       // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
         for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + 4 * fh) * PATCH_PITCH + j * 32 + fr] = acc[step][j][e];
     }
   };
-  epilogue_wave<T, EPI, 4>(g, to_patch, patch, m0 + wr * 128, n0 + wc * 64, lane);
+  epilogue_wave<T, EPI, 4, WROWS>(g, to_patch, patch, m0 + wr * WROWS, n0 + wc * 64, lane);
 #ifdef GPT_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -283,22 +292,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
 #endif
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, int RT>
 int launch256(const GemmArgs<T>& g, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm256_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+    if (hipFuncSetAttribute((const void*)gemm256_kernel<T, EPI, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
         hipSuccess) {
       gpt_set_error("gpt_gemm_nt: cannot reserve %d bytes of LDS", LDS_BYTES);
       return -1;
     }
     attr_set = true;
   }
-  const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+  const int tiles = ((g.M + 32 * RT - 1) / (32 * RT)) * ((g.N + 255) / 256);
   const int grid = tiles;
   const bool rec = g_prof.on && g_prof.n < GemmProf::CAP;
   if (rec) (void)hipEventRecord(g_prof.ev[g_prof.n][0], s);
-  hipLaunchKernelGGL((gemm256_kernel<T, EPI>), dim3(grid), dim3(512), LDS_BYTES, s, g);
+  hipLaunchKernelGGL((gemm256_kernel<T, EPI, RT>), dim3(grid), dim3(512), LDS_BYTES, s, g);
   if (rec) {
     (void)hipEventRecord(g_prof.ev[g_prof.n][1], s);
     g_prof.flops[g_prof.n++] = 2.0 * g.M * g.N * g.K;
@@ -306,16 +315,16 @@ int launch256(const GemmArgs<T>& g, hipStream_t s) {
   return gpt_launch_status("gpt_gemm_nt");
 }
 
-template <typename T>
+template <typename T, int RT>
 int dispatch256(const GemmArgs<T>& g, int epi, hipStream_t s) {
   switch (epi) {
-    case GPT_EPI_STORE: return launch256<T, GPT_EPI_STORE>(g, s);
-    case GPT_EPI_GELU: return launch256<T, GPT_EPI_GELU>(g, s);
-    case GPT_EPI_RESADD: return launch256<T, GPT_EPI_RESADD>(g, s);
-    case GPT_EPI_STORE_F32: return launch256<T, GPT_EPI_STORE_F32>(g, s);
-    case GPT_EPI_GELU_AUX: return launch256<T, GPT_EPI_GELU_AUX>(g, s);
-    case GPT_EPI_DGELU: return launch256<T, GPT_EPI_DGELU>(g, s);
-    case GPT_EPI_ACCUM_F32: return launch256<T, GPT_EPI_ACCUM_F32>(g, s);
+    case GPT_EPI_STORE: return launch256<T, GPT_EPI_STORE, RT>(g, s);
+    case GPT_EPI_GELU: return launch256<T, GPT_EPI_GELU, RT>(g, s);
+    case GPT_EPI_RESADD: return launch256<T, GPT_EPI_RESADD, RT>(g, s);
+    case GPT_EPI_STORE_F32: return launch256<T, GPT_EPI_STORE_F32, RT>(g, s);
+    case GPT_EPI_GELU_AUX: return launch256<T, GPT_EPI_GELU_AUX, RT>(g, s);
+    case GPT_EPI_DGELU: return launch256<T, GPT_EPI_DGELU, RT>(g, s);
+    case GPT_EPI_ACCUM_F32: return launch256<T, GPT_EPI_ACCUM_F32, RT>(g, s);
   }
   gpt_set_error("gpt_gemm_nt: unknown epilogue %d", epi);
   return -1;
@@ -323,7 +332,10 @@ int dispatch256(const GemmArgs<T>& g, int epi, hipStream_t s) {
 
 }  // namespace
 
-int gemm256_bf16(const GemmArgs<bf16_t>& g, int epi, hipStream_t s) { return dispatch256<bf16_t>(g, epi, s); }
-int gemm256_f32(const GemmArgs<float>& g, int epi, hipStream_t s) { return dispatch256<float>(g, epi, s); }
+// rt = 16-row tiles per wave: 8 (256-row block tiles) or 7 (224-row)
+int gemm256_bf16(const GemmArgs<bf16_t>& g, int epi, int rt, hipStream_t s) {
+  return rt == 7 ? dispatch256<bf16_t, 7>(g, epi, s) : dispatch256<bf16_t, 8>(g, epi, s);
+}
+int gemm256_f32(const GemmArgs<float>& g, int epi, hipStream_t s) { return dispatch256<float, 8>(g, epi, s); }
 
 }  // namespace gemmk

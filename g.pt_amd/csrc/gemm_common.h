@@ -172,7 +172,8 @@ __device__ __forceinline__ void epi_store8(const GemmArgs<T>& g, int m, int n, c
 }
 
 // to_patch(step): writes rows [32 step, 32 step + 32) x 64 columns of the wave's accumulators to patch[row][col]
-template <typename T, int EPI, int NI, typename ToPatch>
+// ROWS <= 32 NI: rows of the wave's block that exist (a multiple of 8; the last step may be partly empty)
+template <typename T, int EPI, int NI, int ROWS = 32 * NI, typename ToPatch>
 __device__ __forceinline__ void epilogue_wave(const GemmArgs<T>& g, ToPatch&& to_patch, float* patch, int mrow0,
                                               int ncol0, int lane) {
   const int pr = lane >> 3, pc8 = (lane & 7) * 8;
@@ -186,12 +187,12 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs<T>& g, ToPatch&& to
   // hipcc's wait for it (s_waitcnt vmcnt(0), repeated after every branch) drains the stores of every step
   asm volatile("" : "+v"(b0.x), "+v"(b0.y), "+v"(b0.z), "+v"(b0.w), "+v"(b1.x), "+v"(b1.y), "+v"(b1.z), "+v"(b1.w));
   // wave-uniform: the wave's whole (32 NI) x 64 block lies inside the matrix -> straight-line code, counted waits
-  const bool full = __builtin_amdgcn_readfirstlane((mrow0 + 32 * NI <= g.M && ncol0 + 64 <= g.N) ? 1 : 0) != 0;
+  const bool full = __builtin_amdgcn_readfirstlane((mrow0 + ROWS <= g.M && ncol0 + 64 <= g.N) ? 1 : 0) != 0;
   if (full) {
     EpiPre pre[2][4];
     if constexpr (epi_reads<EPI>) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) epi_load8<T, EPI>(g, mrow0 + p * 8 + pr, n, pre[0][p]);
+      for (int p = 0; p < 4; ++p) epi_load8<T, EPI>(g, mrow0 + p * 8 + pr, n, pre[0][p]);   // ROWS >= 32
     }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -200,11 +201,13 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs<T>& g, ToPatch&& to
       if constexpr (epi_reads<EPI>) {
         if (i + 1 < NI) {
 #pragma unroll
-          for (int p = 0; p < 4; ++p) epi_load8<T, EPI>(g, mrow0 + (i + 1) * 32 + p * 8 + pr, n, pre[(i + 1) & 1][p]);
+          for (int p = 0; p < 4; ++p)
+            if ((i + 1) * 32 + p * 8 < ROWS) epi_load8<T, EPI>(g, mrow0 + (i + 1) * 32 + p * 8 + pr, n, pre[(i + 1) & 1][p]);
         }
       }
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
+        if (i * 32 + p * 8 >= ROWS) continue;
         const int row = p * 8 + pr;
         const float4 v0 = *reinterpret_cast<const float4*>(patch + row * PATCH_PITCH + pc8);
         const float4 v1 = *reinterpret_cast<const float4*>(patch + row * PATCH_PITCH + pc8 + 4);
@@ -221,6 +224,7 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs<T>& g, ToPatch&& to
     WAVE_LDS_ORDER();
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
+      if (i * 32 + p * 8 >= ROWS) continue;
       const int row = p * 8 + pr;
       const int m = mrow0 + i * 32 + row;
       const float4 v0 = *reinterpret_cast<const float4*>(patch + row * PATCH_PITCH + pc8);

@@ -45,7 +45,10 @@ def build(case, dtype="fp32", seed=0):
 # ------------------------------------------------------------------------------------------ kernels
 @pytest.mark.parametrize("dtype,tol", [("fp32", 2e-5), ("bf16", 1e-2)])
 @pytest.mark.parametrize("M,N,K", [(104, 192, 192), (104, 576, 192), (300, 768, 192), (128, 128, 64), (1664, 1536, 1536),
-                                   (77, 136, 256)])
+                                   (77, 136, 256),
+                                   # the 256 x 256 kernel: 224-row tiles with a ragged last row tile (8320 = 37.1 x 224),
+                                   # 256-row tiles filling whole rounds, and a row tail handed to the ring kernels
+                                   (8320, 1536, 256), (4096, 4096, 128), (8320, 6144, 128)])
 def test_gemm_epilogues(dtype, tol, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
     A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
