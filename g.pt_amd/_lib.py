@@ -9,8 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPT_HIP_LIB") or os.path.join(_HERE, "lib", "libgpt_hip.so")   # override: kernel experiments
 
 F32, BF16 = 0, 1
-EPI_STORE, EPI_GELU, EPI_RESADD, EPI_STORE_F32, EPI_GELU_AUX, EPI_DGELU, EPI_ACCUM_F32, EPI_RESADD_STATS, EPI_LN_STORE, \
-    EPI_LN_GELU = range(10)
+EPI_STORE, EPI_GELU, EPI_RESADD, EPI_STORE_F32, EPI_GELU_AUX, EPI_DGELU, EPI_ACCUM_F32 = range(7)
 MAX_TOKENS = 40
 SRC_X, SRC_XPREV, SRC_SCALAR = 0, 1, 2
 NCOEF = 8
@@ -59,7 +58,6 @@ class Workspace(C.Structure):
 _PROTOS = {
     "gpt_abi_version": ([], i32),
     "gpt_gemm_nt": ([i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp], i32),
-    "gpt_gemm_nt_ln": ([i32, vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, i32, vp, vp, vp, vp], i32),
     "gpt_gemm_tn": ([vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp], i32),
     "gpt_gemm_prof_enable": ([i32], i32),
     "gpt_gemm_prof_collect": ([C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)], i32),

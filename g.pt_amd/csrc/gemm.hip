@@ -297,15 +297,13 @@ int dispatch(const GemmArgs<T>& g, int epi, hipStream_t s) {
     if constexpr (sizeof(T) == 2) rc = gemm256_bf16(head, epi, rt, s);
     else rc = gemm256_f32(head, epi, s);
     if (rc != 0 || m_main == g.M) return rc;
-    const bool c32 = epi == GPT_EPI_RESADD || epi == GPT_EPI_STORE_F32 || epi == GPT_EPI_ACCUM_F32 || epi == GPT_EPI_RESADD_STATS;
+    const bool c32 = epi == GPT_EPI_RESADD || epi == GPT_EPI_STORE_F32 || epi == GPT_EPI_ACCUM_F32;
     const bool aux32 = epi == GPT_EPI_RESADD;
     GemmArgs<T> tail = g;
     tail.M = g.M - m_main;
     tail.A = g.A + (int64_t)m_main * g.lda;
     tail.C = (char*)g.C + (int64_t)m_main * g.ldc * (c32 ? 4 : sizeof(T));
     if (g.aux) tail.aux = (char*)g.aux + (int64_t)m_main * g.ldaux * (aux32 ? 4 : sizeof(T));
-    if (g.stats) tail.stats = g.stats + 2 * (int64_t)m_main;
-    if (g.copy) tail.copy = (char*)g.copy + (int64_t)m_main * g.ldc * sizeof(T);
     return dispatch_ring<T>(tail, epi, s);
   }
   return dispatch_ring<T>(g, epi, s);
@@ -321,9 +319,6 @@ int dispatch_ring(const GemmArgs<T>& g, int epi, hipStream_t s) {
     case GPT_EPI_GELU_AUX: return launch<T, GPT_EPI_GELU_AUX>(g, s);
     case GPT_EPI_DGELU: return launch<T, GPT_EPI_DGELU>(g, s);
     case GPT_EPI_ACCUM_F32: return launch<T, GPT_EPI_ACCUM_F32>(g, s);
-    case GPT_EPI_RESADD_STATS: return launch<T, GPT_EPI_RESADD_STATS>(g, s);
-    case GPT_EPI_LN_STORE: return launch<T, GPT_EPI_LN_STORE>(g, s);
-    case GPT_EPI_LN_GELU: return launch<T, GPT_EPI_LN_GELU>(g, s);
   }
   gpt_set_error("gpt_gemm_nt: unknown epilogue %d", epi);
   return -1;
@@ -358,26 +353,6 @@ extern "C" int gpt_gemm_prof_collect(double* total_ms, double* total_flops, int*
   }
   *total_ms = ms; *total_flops = fl; *launches = g_prof.n;
   return 0;
-}
-
-extern "C" int gpt_gemm_nt_ln(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C,
-                              int64_t ldc, int M, int N, int K, int epilogue, float* stats, const float* colsum, void* copy,
-                              void* stream) {
-  GPT_REQUIRE(dtype == GPT_BF16, "gpt_gemm_nt_ln: bf16 only (fp32 is the parity mode and keeps its LayerNorm kernels)");
-  GPT_REQUIRE(epilogue == GPT_EPI_RESADD_STATS || epilogue == GPT_EPI_LN_STORE || epilogue == GPT_EPI_LN_GELU,
-              "gpt_gemm_nt_ln: epilogue %d is not a LayerNorm-folding epilogue", epilogue);
-  GPT_REQUIRE(M > 0 && N > 0 && K > 0 && K % 32 == 0, "gpt_gemm_nt_ln: bad problem M=%d N=%d K=%d", M, N, K);
-  GPT_REQUIRE(A && W && C && stats, "gpt_gemm_nt_ln: null operand");
-  GPT_REQUIRE(lda >= K && ldw >= K && ldc >= N && (lda * 2) % 16 == 0 && (ldw * 2) % 16 == 0, "gpt_gemm_nt_ln: bad leading dimensions");
-  GPT_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)C % 16) == 0 && ((uintptr_t)bias % 16) == 0 &&
-                  ((uintptr_t)stats % 8) == 0 && ((uintptr_t)colsum % 16) == 0 && ((uintptr_t)copy % 16) == 0,
-              "gpt_gemm_nt_ln: operands must be 16-byte aligned");
-  GPT_REQUIRE(N % 8 == 0 && ldc % 8 == 0, "gpt_gemm_nt_ln: N and ldc must be multiples of 8 (vector epilogue)");
-  if (epilogue == GPT_EPI_RESADD_STATS) GPT_REQUIRE(copy, "gpt_gemm_nt_ln: RESADD_STATS needs the copy buffer");
-  else GPT_REQUIRE(colsum && bias, "gpt_gemm_nt_ln: the LN epilogues need colsum and the folded bias");
-  GemmArgs<bf16_t> g{(const bf16_t*)A, (const bf16_t*)W, bias, C, nullptr, lda, ldw, ldc, 0, M, N, K};
-  g.stats = stats; g.colsum = colsum; g.copy = copy;
-  return dispatch<bf16_t>(g, epilogue, (hipStream_t)stream);
 }
 
 extern "C" int gpt_gemm_nt(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,

@@ -325,9 +325,6 @@ int dispatch256(const GemmArgs<T>& g, int epi, hipStream_t s) {
     case GPT_EPI_GELU_AUX: return launch256<T, GPT_EPI_GELU_AUX, RT>(g, s);
     case GPT_EPI_DGELU: return launch256<T, GPT_EPI_DGELU, RT>(g, s);
     case GPT_EPI_ACCUM_F32: return launch256<T, GPT_EPI_ACCUM_F32, RT>(g, s);
-    case GPT_EPI_RESADD_STATS: return launch256<T, GPT_EPI_RESADD_STATS, RT>(g, s);
-    case GPT_EPI_LN_STORE: return launch256<T, GPT_EPI_LN_STORE, RT>(g, s);
-    case GPT_EPI_LN_GELU: return launch256<T, GPT_EPI_LN_GELU, RT>(g, s);
   }
   gpt_set_error("gpt_gemm_nt: unknown epilogue %d", epi);
   return -1;

@@ -16,16 +16,7 @@ struct GemmArgs {
   void* aux;
   int64_t lda, ldw, ldc, ldaux;
   int M, N, K;
-  // LayerNorm folding (gpt_gemm_nt_ln): row sums [M][2] = (sum x, sum x^2), column sums of the gamma-scaled weight [N],
-  // low-precision copy of the fp32 output [M, ldc]
-  float* stats = nullptr;
-  const float* colsum = nullptr;
-  void* copy = nullptr;
 };
-
-// epilogues of gpt_gemm_nt_ln (see include/gpt_hip.h)
-template <int EPI>
-constexpr bool epi_ln = EPI == GPT_EPI_LN_STORE || EPI == GPT_EPI_LN_GELU;
 
 template <typename T>
 __device__ __forceinline__ void store4(T* p, const float4& v) {
@@ -138,8 +129,7 @@ __device__ __forceinline__ float4 dgelu4(const float4& v, const float4& pre) {
 // What an epilogue READS for 8 consecutive columns of one row (the residual, the running sum or the pre-activation).
 // Loaded one 32-row step ahead of its use so that no wait on it ever covers the stores issued after it.
 template <int EPI>
-constexpr bool epi_reads = EPI == GPT_EPI_RESADD || EPI == GPT_EPI_ACCUM_F32 || EPI == GPT_EPI_DGELU ||
-                           EPI == GPT_EPI_RESADD_STATS || epi_ln<EPI>;
+constexpr bool epi_reads = EPI == GPT_EPI_RESADD || EPI == GPT_EPI_ACCUM_F32 || EPI == GPT_EPI_DGELU;
 struct EpiPre {
   float4 a, b;
 };
@@ -151,11 +141,7 @@ __device__ __forceinline__ void epi_load8(const GemmArgs<T>& g, int m, int n, Ep
     const float* rp = g.aux ? (const float*)g.aux + ai : (const float*)g.C + ci;
     p.a = reinterpret_cast<const float4*>(rp)[0];
     p.b = reinterpret_cast<const float4*>(rp)[1];
-  } else if constexpr (epi_ln<EPI>) {
-    const float2 st = reinterpret_cast<const float2*>(g.stats)[m];     // (sum x, sum x^2) of the row over its K features
-    p.a.x = st.x;
-    p.a.y = st.y;
-  } else if constexpr (EPI == GPT_EPI_ACCUM_F32 || EPI == GPT_EPI_RESADD_STATS) {
+  } else if constexpr (EPI == GPT_EPI_ACCUM_F32) {
     const float* c = (const float*)g.C + ci;
     p.a = reinterpret_cast<const float4*>(c)[0];
     p.b = reinterpret_cast<const float4*>(c)[1];
@@ -164,60 +150,17 @@ __device__ __forceinline__ void epi_load8(const GemmArgs<T>& g, int m, int n, Ep
   }
 }
 
-// per-lane column vectors of the epilogue: bias (or the folded LayerNorm constant) and, for the LN epilogues, the column sums
-struct ColVec {
-  float4 b0, b1, s0, s1;
-};
-__device__ __forceinline__ float4 fma4(float a, const float4& x, const float4& y) {
-  return make_float4(fmaf(a, x.x, y.x), fmaf(a, x.y, y.y), fmaf(a, x.z, y.z), fmaf(a, x.w, y.w));
-}
-// Row sums of the 8 lanes that share a row (lane & 7 = column group), added by the lane of column group 0.
-// Called by all 64 lanes (invalid lanes pass zeros and valid = false).
-__device__ __forceinline__ void epi_row_stats(float* stats, int m, bool valid, const float4& o0, const float4& o1) {
-  float s1 = ((o0.x + o0.y) + (o0.z + o0.w)) + ((o1.x + o1.y) + (o1.z + o1.w));
-  float s2 = ((o0.x * o0.x + o0.y * o0.y) + (o0.z * o0.z + o0.w * o0.w)) + ((o1.x * o1.x + o1.y * o1.y) + (o1.z * o1.z + o1.w * o1.w));
-#pragma unroll
-  for (int o = 1; o < 8; o <<= 1) {
-    s1 += __shfl_xor(s1, o, 64);
-    s2 += __shfl_xor(s2, o, 64);
-  }
-  if (valid && (__lane_id() & 7) == 0) {
-    unsafeAtomicAdd(stats + 2 * (int64_t)m, s1);
-    unsafeAtomicAdd(stats + 2 * (int64_t)m + 1, s2);
-  }
-}
-
-// 8 consecutive columns of row m starting at column n (n % 8 == 0; m < M, n < N; N % 8 == 0); v0 | v1 = raw accumulators.
-// Returns through o0 | o1 what was written as the fp32 output (RESADD_STATS only: the caller adds the row statistics).
+// 8 consecutive columns of row m starting at column n (n % 8 == 0; m < M, n < N; N % 8 == 0); a | b = acc + bias
 template <typename T, int EPI>
-__device__ __forceinline__ void epi_store8(const GemmArgs<T>& g, int m, int n, const float4& v0, const float4& v1, const ColVec& cv,
-                                           const EpiPre& p, float4& o0, float4& o1) {
+__device__ __forceinline__ void epi_store8(const GemmArgs<T>& g, int m, int n, const float4& a, const float4& b, const EpiPre& p) {
   const int64_t ci = (int64_t)m * g.ldc + n;
   const int64_t ai = (int64_t)m * g.ldaux + n;
-  if constexpr (epi_ln<EPI>) {
-    // LayerNorm folded into the contraction: y = rstd (acc - mean colsum) + const, acc = x . (gamma W)^T on the raw rows
-    const float inv_k = 1.0f / (float)g.K;
-    const float mean = p.a.x * inv_k;
-    const float var = fmaxf(p.a.y * inv_k - mean * mean, 0.f);
-    const float rstd = rsqrtf(var + 1e-5f);
-    const float nm = -mean;
-    const float4 a = fma4(rstd, fma4(nm, cv.s0, v0), cv.b0), b = fma4(rstd, fma4(nm, cv.s1, v1), cv.b1);
-    if constexpr (EPI == GPT_EPI_LN_STORE) store8<T>((T*)g.C + ci, a, b);
-    else store8<T>((T*)g.C + ci, gelu4<T>(a), gelu4<T>(b));
-    return;
-  }
-  const float4 a = add4(v0, cv.b0), b = add4(v1, cv.b1);
   if constexpr (EPI == GPT_EPI_STORE) {
     store8<T>((T*)g.C + ci, a, b);
   } else if constexpr (EPI == GPT_EPI_GELU) {
     store8<T>((T*)g.C + ci, gelu4<T>(a), gelu4<T>(b));
   } else if constexpr (EPI == GPT_EPI_RESADD || EPI == GPT_EPI_ACCUM_F32) {
     store8<float>((float*)g.C + ci, add4(p.a, a), add4(p.b, b));
-  } else if constexpr (EPI == GPT_EPI_RESADD_STATS) {
-    o0 = add4(p.a, a);
-    o1 = add4(p.b, b);
-    store8<float>((float*)g.C + ci, o0, o1);
-    store8<T>((T*)g.copy + ci, o0, o1);
   } else if constexpr (EPI == GPT_EPI_STORE_F32) {
     store8<float>((float*)g.C + ci, a, b);
   } else if constexpr (EPI == GPT_EPI_GELU_AUX) {
@@ -243,14 +186,6 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs<T>& g, ToPatch&& to
   // the bias is consumed HERE as far as the compiler can tell: otherwise its first use sits inside the steps below and
   // hipcc's wait for it (s_waitcnt vmcnt(0), repeated after every branch) drains the stores of every step
   asm volatile("" : "+v"(b0.x), "+v"(b0.y), "+v"(b0.z), "+v"(b0.w), "+v"(b1.x), "+v"(b1.y), "+v"(b1.z), "+v"(b1.w));
-  ColVec cv{b0, b1, make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-  if constexpr (epi_ln<EPI>) {
-    if (n < g.N) {
-      cv.s0 = reinterpret_cast<const float4*>(g.colsum + n)[0];
-      cv.s1 = reinterpret_cast<const float4*>(g.colsum + n)[1];
-    }
-    asm volatile("" : "+v"(cv.s0.x), "+v"(cv.s0.y), "+v"(cv.s0.z), "+v"(cv.s0.w), "+v"(cv.s1.x), "+v"(cv.s1.y), "+v"(cv.s1.z), "+v"(cv.s1.w));
-  }
   // wave-uniform: the wave's whole (32 NI) x 64 block lies inside the matrix -> straight-line code, counted waits
   const bool full = __builtin_amdgcn_readfirstlane((mrow0 + ROWS <= g.M && ncol0 + 64 <= g.N) ? 1 : 0) != 0;
   if (full) {
@@ -276,9 +211,7 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs<T>& g, ToPatch&& to
         const int row = p * 8 + pr;
         const float4 v0 = *reinterpret_cast<const float4*>(patch + row * PATCH_PITCH + pc8);
         const float4 v1 = *reinterpret_cast<const float4*>(patch + row * PATCH_PITCH + pc8 + 4);
-        float4 o0, o1;
-        epi_store8<T, EPI>(g, mrow0 + i * 32 + row, n, v0, v1, cv, pre[i & 1][p], o0, o1);
-        if constexpr (EPI == GPT_EPI_RESADD_STATS) epi_row_stats(g.stats, mrow0 + i * 32 + row, true, o0, o1);
+        epi_store8<T, EPI>(g, mrow0 + i * 32 + row, n, add4(v0, b0), add4(v1, b1), pre[i & 1][p]);
       }
       WAVE_LDS_ORDER();
     }
@@ -296,14 +229,11 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs<T>& g, ToPatch&& to
       const int m = mrow0 + i * 32 + row;
       const float4 v0 = *reinterpret_cast<const float4*>(patch + row * PATCH_PITCH + pc8);
       const float4 v1 = *reinterpret_cast<const float4*>(patch + row * PATCH_PITCH + pc8 + 4);
-      const bool ok = m < g.M && n < g.N;
-      float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0;
-      if (ok) {
+      if (m < g.M && n < g.N) {
         EpiPre pre;
         if constexpr (epi_reads<EPI>) epi_load8<T, EPI>(g, m, n, pre);
-        epi_store8<T, EPI>(g, m, n, v0, v1, cv, pre, o0, o1);
+        epi_store8<T, EPI>(g, m, n, add4(v0, b0), add4(v1, b1), pre);
       }
-      if constexpr (EPI == GPT_EPI_RESADD_STATS) epi_row_stats(g.stats, m, ok, o0, o1);
     }
     WAVE_LDS_ORDER();
   }

@@ -34,10 +34,6 @@ extern "C" {
 #define GPT_EPI_GELU_AUX 4  /* aux(dtype) = acc + bias ; C(dtype) = gelu(aux)  (training: keeps pre-activation) */
 #define GPT_EPI_DGELU 5     /* C(dtype)  = acc * gelu'(aux)              (backward of GELU) */
 #define GPT_EPI_ACCUM_F32 6 /* C(fp32)  += acc                           (gradient accumulation) */
-/* gpt_gemm_nt_ln only (LayerNorm folded into the neighbouring contractions, bf16 inference): */
-#define GPT_EPI_RESADD_STATS 7 /* C(fp32) += acc + bias in place; copy(dtype) = C; stats[m] += (sum_n C, sum_n C^2) */
-#define GPT_EPI_LN_STORE 8     /* C(dtype) = rstd_m (acc - mean_m colsum_n) + bias_n,  mean / rstd from stats[m] over K */
-#define GPT_EPI_LN_GELU 9      /* C(dtype) = gelu(the same)                                                        */
 
 const char* gpt_last_error(void);
 int gpt_abi_version(void);
@@ -50,18 +46,6 @@ int gpt_abi_version(void);
 int gpt_gemm_nt(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                 void* C, int64_t ldc, void* aux, int64_t ldaux, int M, int N, int K, int epilogue,
                 void* stream);
-
-/* gpt_gemm_nt with the LayerNorm that FOLLOWS a residual Linear folded away (Block.forward, transformer.py:69-72:
- * x = x + f(..); h = ln(x); y = Linear(h)).  With W' = W diag(gamma), colsum_n = sum_k W'[n,k] and
- * bias'_n = sum_k beta_k W[n,k] + bias_n:   Linear(ln(x))[m,n] = rstd_m (x_m . W'_n - mean_m colsum_n) + bias'_n.
- *   GPT_EPI_RESADD_STATS  (the residual Linear): besides the fp32 update in place it writes the `dtype` copy of the new
- *                         x (operand of the next contraction) and adds the row sums to stats[M][2] (zeroed by the caller);
- *   GPT_EPI_LN_STORE / GPT_EPI_LN_GELU (the following Linear on the raw copy): A = copy, W = W', bias = bias',
- *                         colsum, stats; the LayerNorm dimension is K.
- * The LayerNorm kernel between the two (one pass over [M, d]) disappears.  stats / colsum / copy: see the epilogues. */
-int gpt_gemm_nt_ln(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C,
-                   int64_t ldc, int M, int N, int K, int epilogue, float* stats, const float* colsum, void* copy,
-                   void* stream);
 
 /* C[I, J] (+)= P[R, I]^T . Q[R, J]: bf16 operands contracted over their ROW index, fp32 output (accumulate != 0:
  * C += ...).  The weight gradient dW = dY^T . X that autograd derives for every nn.Linear of the trunk

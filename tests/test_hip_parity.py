@@ -87,46 +87,6 @@ def test_gemm_epilogues(dtype, tol, M, N, K):
     assert rel_err(out.float().cpu(), torch.nn.functional.gelu(ref)) < tol
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 768, 192), (8320, 1536, 256), (4096, 4096, 128)])
-def test_gemm_layernorm_folding(M, N, K):
-    """gpt_gemm_nt_ln: the residual Linear that also emits the bf16 copy and the row sums, and the Linear that applies the
-    folded LayerNorm in its epilogue, against ln + Linear in float64."""
-    g = torch.Generator().manual_seed(M + N + K)
-    lib = L.lib()
-    # 1. x += A W^T + b, copy, row sums
-    A, W = torch.randn(M, K, generator=g).bfloat16(), (torch.randn(N, K, generator=g) * 0.05).bfloat16()
-    bias, x0 = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
-    Ad, Wd, bd, xd = A.to(DEV), W.to(DEV), bias.to(DEV), x0.to(DEV)
-    stats = torch.zeros(M, 2, device=DEV)
-    copy = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    L.check(lib.gpt_gemm_nt_ln(L.BF16, L.ptr(Ad), K, L.ptr(Wd), K, L.ptr(bd), L.ptr(xd), N, M, N, K, L.EPI_RESADD_STATS,
-                               L.ptr(stats), None, L.ptr(copy), L.stream()), "resadd_stats")
-    ref = x0.double() + A.double() @ W.double().t() + bias.double()
-    assert rel_err(xd.cpu(), ref) < 1e-5
-    assert torch.equal(copy.cpu(), xd.cpu().bfloat16())
-    np.testing.assert_allclose(stats[:, 0].cpu().numpy(), ref.sum(1).numpy(), rtol=1e-4, atol=1e-2)
-    np.testing.assert_allclose(stats[:, 1].cpu().numpy(), (ref * ref).sum(1).numpy(), rtol=1e-4)
-    # 2. Linear(ln(x)) on the raw bf16 rows
-    X = (torch.randn(M, K, generator=g) * (1 + torch.rand(K, generator=g)) + 0.3).bfloat16()
-    gamma, beta = 1 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
-    Wf = torch.randn(N, K, generator=g) * 0.05
-    Wp = (Wf * gamma).bfloat16()
-    colsum = Wp.float().sum(1)
-    bias_f = (Wf.double() @ beta.double() + bias.double()).float()
-    Xf = X.double()
-    st = torch.stack([Xf.sum(1), (Xf * Xf).sum(1)], 1).float().to(DEV)
-    ln = torch.nn.functional.layer_norm(Xf, (K,), gamma.double(), beta.double(), 1e-5)
-    want = ln @ Wf.double().t() + bias.double()
-    Xd, Wpd, csd, bfd = X.to(DEV), Wp.to(DEV), colsum.to(DEV), bias_f.to(DEV)
-    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    for epi, fn in ((L.EPI_LN_STORE, lambda v: v), (L.EPI_LN_GELU, torch.nn.functional.gelu)):
-        L.check(lib.gpt_gemm_nt_ln(L.BF16, L.ptr(Xd), K, L.ptr(Wpd), K, L.ptr(bfd), L.ptr(out), N, M, N, K, epi, L.ptr(st),
-                                   L.ptr(csd), None, L.stream()), "ln_epi")
-        assert rel_err(out.float().cpu(), fn(want)) < 1.5e-2
-    assert lib.gpt_gemm_nt_ln(L.F32, L.ptr(Xd), K, L.ptr(Wpd), K, L.ptr(bfd), L.ptr(out), N, M, N, K, L.EPI_LN_STORE, L.ptr(st),
-                              L.ptr(csd), None, L.stream()) != 0
-
-
 def test_gemm_gelu_bf16_range():
     """bf16 GELU epilogue (x * sigmoid(fitted odd polynomial)) against the exact erf GELU over [-30, 30], outliers included:
     error <= one bf16 rounding of the result + 2.6e-5 (the fit's bound, gemm_common.h)."""
