@@ -97,7 +97,7 @@ class SampleRunner:
             self.cursor = last - 1 if last > 0 else n - 1
 
 
-def cpu_baseline(case, seconds_target=20.0):
+def cpu_baseline(case, seconds_target=15.0):
     """The oracle's denoising step (forward + posterior update) on the host cores, bounded sample."""
     from oracle import denoiser as od, diffusion as odf
     c = CASES[case]
@@ -122,7 +122,7 @@ def cpu_baseline(case, seconds_target=20.0):
     t0 = time.perf_counter()
     step(998)
     one = time.perf_counter() - t0
-    reps = max(2, min(12, int(seconds_target / max(one, 1e-3))))
+    reps = max(2, min(100, int(seconds_target / max(one, 1e-3))))     # a bounded sample: about 15 s of CPU work
     t0 = time.perf_counter()
     for i in range(reps):
         x = step(997 - i)
