@@ -9,10 +9,11 @@
 //  * a K-tile is 64 ROWS r of the operands; a half-tile holds, for each of them, 128 CONTIGUOUS columns of the block
 //    tile (full 256-byte runs for the LDS-DMA) = 64 LDS rows of 256 bytes; a wave therefore owns output rows
 //    {128 hi + 64 wr + [0, 64)} and columns {128 hj + 32 wc + [0, 32)} for the halves hi, hj = 0, 1;
-//  * the MFMA operands (8 consecutive r for one column) are gathered with ds_read_b64_tr_b16, gfx950's transposing
-//    LDS read: a 16-lane group reads a 4-row x 16-column block and every lane receives one COLUMN of it, so two
-//    reads give a lane its 8 k-values.  16-byte chunk c of LDS row r is stored at chunk c ^ ((r & 3) << 2): the four
-//    rows of a block then sit in four different 64-byte bank groups and the read is conflict-free.
+//  * the MFMA operands (16x16x32: 8 consecutive r for one column) are gathered with ds_read_b64_tr_b16, gfx950's
+//    transposing LDS read: a 16-lane group reads a 4-row x 16-column block and every lane receives one COLUMN of it, so
+//    two reads give a lane its 8 k-values.  16-byte chunk c of LDS row r is stored at chunk
+//    c ^ ((r & 3) << 2) ^ (((r >> 3) & 1) << 1): the four rows of a block sit in four different 64-byte bank groups and
+//    the two groups of a 32-lane half (rows 8 apart, same columns) in the two 32-byte halves of them: conflict-free.
 // Needs R % 64 == 0, I % 256 == 0, J % 256 == 0 (the host falls back to transposes + the NT kernel otherwise).
 #include "gemm_common.h"
 #include <stdlib.h>
@@ -28,18 +29,13 @@ constexpr int TLDS_BYTES = 2 * TBUF;  // 128 KiB
 typedef short v4s __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4s* lds_v4s_ptr;
 
-// the 8 k-values (rows r0 .. r0+7 of the half-tile, r0 = 16 ks + 8 (lane >> 5)) of this lane's column
-__device__ __forceinline__ u32x4 tr_frag(const char* base_lo, int ks) {
-#ifdef GPT_TN_EXP_B128   // timing experiment (wrong numerics): one ds_read_b128 instead of the two transposing reads
-  return *reinterpret_cast<const u32x4*>((const char*)((uintptr_t)(base_lo + ks * 16 * TRB) & ~(uintptr_t)15));
-#endif
-  // base_lo already holds this lane's row (8 (g >> 1) + q) * TRB + swizzled chunk + 8 (p & 1); rows +4 are 4 TRB on
-  const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(base_lo + ks * 16 * TRB));
-  const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(base_lo + ks * 16 * TRB + 4 * TRB));
+// the 8 k-values (LDS rows 32 kk + 8 (lane >> 4) + [0, 8)) of this lane's column: two transposing reads 4 rows apart
+__device__ __forceinline__ u32x4 tr_frag(const char* base, int kk) {
+  const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(base + kk * 32 * TRB));
+  const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(base + kk * 32 * TRB + 4 * TRB));
   typedef short v8s __attribute__((ext_vector_type(8)));
   const v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);   // register concatenation, no VALU
-  const u32x4 out = __builtin_bit_cast(u32x4, both);
-  return out;
+  return __builtin_bit_cast(u32x4, both);
 }
 
 // ksplit > 1 (accumulating epilogue only): the R range is cut into ksplit contiguous spans, one workgroup per (span, tile),
@@ -74,17 +70,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(GemmArgs<bf16_t> g, 
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     const int lr = wid * 8 + p * 4 + (lane >> 4);
-    const int lc = (lane & 15) ^ ((lr & 3) << 2);          // logical 16-byte chunk (8 columns) of the 128-column row
+    const int lc = (lane & 15) ^ ((lr & 3) << 2) ^ (((lr >> 3) & 1) << 1);   // logical 16-byte chunk (8 columns) of the 128-column row
     const int e = lc * 8;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-#ifdef GPT_TN_EXP_SRC    // timing experiment (wrong numerics): the NT kernel's source pattern (8 rows x 128 B per instruction)
-      srcP[h][p] = g.A + (int64_t)(m0 % 64 + wid * 16 + p * 8 + (lane >> 3)) * g.lda + (lane & 7) * 8 + h * 64;
-      srcQ[h][p] = g.W + (int64_t)(n0 % 64 + wid * 16 + p * 8 + (lane >> 3)) * g.ldw + (lane & 7) * 8 + h * 64;
-#else
       srcP[h][p] = g.A + ((int64_t)kt0 * 64 + lr) * g.lda + m0 + h * 128 + e;
       srcQ[h][p] = g.W + ((int64_t)kt0 * 64 + lr) * g.ldw + n0 + h * 128 + e;
-#endif
     }
   }
   const int64_t stepP = 64 * g.lda, stepQ = 64 * g.ldw;
@@ -94,13 +85,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(GemmArgs<bf16_t> g, 
     __builtin_amdgcn_global_load_lds((gptr_t)(src[1] + kt * step), (lptr_t)(dst + 1024), 16, 0, 0);
   };
 
-  f32x16 acc[4][2];
+  // 16x16x32 MFMAs (higher sustained clock than 32x32x16, see gemm256.hip): 8 x 4 accumulator tiles of 16 x 16 per wave
+  f32x4 acc[8][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -111,23 +101,40 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(GemmArgs<bf16_t> g, 
       dma(srcP[1], stepP, t, 1);
     }
 
-  // transposed-read addresses: 16-lane group gq reads the block rows 8 (gq >> 1) + q, columns e0 + 16 (gq & 1) + 4 p
+  // transposed-read addresses: 16-lane group gq reads the block rows 8 gq + q (then + 4), columns e0 + 4 p .. + 3
   const int gq = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
-  const int trow = 8 * (gq >> 1) + tq;
   auto tr_off = [&](int e0) {
-    const int e = e0 + 16 * (gq & 1) + 4 * tp;
-    return trow * TRB + (((e >> 3) ^ (tq << 2)) << 4) + 8 * (tp & 1);
+    const int e = e0 + 4 * tp;
+    return (8 * gq + tq) * TRB + (((e >> 3) ^ (tq << 2) ^ ((gq & 1) << 1)) << 4) + 8 * (tp & 1);
   };
-  const int offP[2] = {tr_off(wr * 64), tr_off(wr * 64 + 32)};
-  const int offQ = tr_off(wc * 32);
+  int offP[4], offQ[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) offP[i] = tr_off(wr * 64 + i * 16);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) offQ[j] = tr_off(wc * 32 + j * 16);
 
-  auto mma = [&](const u32x4 (&a)[2][4], const u32x4 (&b)[4], int i0, int j) {
+  // a[i][kk]: row tile i of the P half, b[j][kk]: column tile j of the Q half, kk = 32-deep K step of the 64-row K-tile
+  auto mma = [&](const u32x4 (&a)[4][2], const u32x4 (&b)[2][2], int i0, int j0) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i][ks]),
-                                                                __builtin_bit_cast(bf16x8, b[ks]), acc[i0 + i][j], 0, 0, 0);
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i0 + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i][kk]),
+                                                                       __builtin_bit_cast(bf16x8, b[j][kk]), acc[i0 + i][j0 + j], 0, 0, 0);
+  };
+  auto read_p = [&](u32x4 (&a)[4][2], const char* half) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) a[i][kk] = tr_frag(half + offP[i], kk);
+  };
+  auto read_q = [&](u32x4 (&b)[2][2], const char* half) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) b[j][kk] = tr_frag(half + offQ[j], kk);
   };
 #define SEG_BARRIER()                        \
   do {                                       \
@@ -147,34 +154,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(GemmArgs<bf16_t> g, 
   for (int kt = 0; kt < nk; ++kt) {
     const char* buf = smem + (kt & 1) * TBUF;
     const bool steady = kt + 2 < nk, last = kt + 1 == nk;
-    u32x4 a[2][4], b0[4], b1[4];
+    u32x4 a[4][2], b0[2][2], b1[2][2];
     // ---- P0
     if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     SEG_BARRIER();
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) b0[ks] = tr_frag(buf + 2 * THALF + offQ, ks);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) a[i][ks] = tr_frag(buf + offP[i], ks);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) b1[ks] = tr_frag(buf + 3 * THALF + offQ, ks);
+    read_q(b0, buf + 2 * THALF);
+    read_p(a, buf);
+    read_q(b1, buf + 3 * THALF);
     if (kt >= 1 && !last) dma(srcP[1], stepP, kt + 1, 1);
     SEG_READS_DONE();
     SEG_BARRIER();
     __builtin_amdgcn_s_setprio(1);
     mma(a, b0, 0, 0);
-    mma(a, b1, 0, 1);
+    mma(a, b1, 0, 2);
     __builtin_amdgcn_s_setprio(0);
     // ---- P1
     if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     SEG_BARRIER();
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) a[i][ks] = tr_frag(buf + THALF + offP[i], ks);
+    read_p(a, buf + THALF);
     if (steady) {
       dma(srcP[0], stepP, kt + 2, 0);
       dma(srcQ[0], stepQ, kt + 2, 2);
@@ -183,8 +182,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(GemmArgs<bf16_t> g, 
     SEG_READS_DONE();
     SEG_BARRIER();
     __builtin_amdgcn_s_setprio(1);
-    mma(a, b1, 2, 1);
-    mma(a, b0, 2, 0);
+    mma(a, b1, 4, 2);
+    mma(a, b0, 4, 0);
     __builtin_amdgcn_s_setprio(0);
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
@@ -192,26 +191,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(GemmArgs<bf16_t> g, 
 #undef SEG_READS_DONE
   __syncthreads();
 
-  // epilogue straight from the accumulator layout (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)):
-  // the output is fp32, so every wave instruction reads / writes two full 128-byte lines
-  const int fr = lane & 31, fh = lane >> 5;
+  // epilogue straight from the accumulator layout (16x16 tile: col = lane & 15, row = 4 * (lane >> 4) + reg): the output is
+  // fp32, every wave instruction reads / writes four 64-byte row segments
+  const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      float* c = (float*)g.C + (int64_t)(m0 + (i >> 1) * 128 + wr * 64 + (i & 1) * 32 + 4 * fh) * g.ldc + n0 + j * 128 + wc * 32 + fr;
+    for (int j = 0; j < 4; ++j) {
+      float* c = (float*)g.C + (int64_t)(m0 + (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + 4 * l4) * g.ldc + n0 + (j >> 1) * 128 + wc * 32 +
+                 (j & 1) * 16 + l15;
       if (EPI == GPT_EPI_ACCUM_F32 && ksplit > 1) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) unsafeAtomicAdd(c + (int64_t)((e & 3) + 8 * (e >> 2)) * g.ldc, acc[i][j][e]);
+        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(c + (int64_t)e * g.ldc, acc[i][j][e]);
       } else if constexpr (EPI == GPT_EPI_ACCUM_F32) {
-        float old[16];
+        float old[4];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) old[e] = c[(int64_t)((e & 3) + 8 * (e >> 2)) * g.ldc];
+        for (int e = 0; e < 4; ++e) old[e] = c[(int64_t)e * g.ldc];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) c[(int64_t)((e & 3) + 8 * (e >> 2)) * g.ldc] = old[e] + acc[i][j][e];
+        for (int e = 0; e < 4; ++e) c[(int64_t)e * g.ldc] = old[e] + acc[i][j][e];
       } else {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) c[(int64_t)((e & 3) + 8 * (e >> 2)) * g.ldc] = acc[i][j][e];
+        for (int e = 0; e < 4; ++e) c[(int64_t)e * g.ldc] = acc[i][j][e];
       }
     }
 }
