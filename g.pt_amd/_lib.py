@@ -58,6 +58,7 @@ class Workspace(C.Structure):
 _PROTOS = {
     "gpt_abi_version": ([], i32),
     "gpt_gemm_nt": ([i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp], i32),
+    "gpt_gemm_set_workspace": ([vp, C.c_size_t], i32),
     "gpt_gemm_tn": ([vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp], i32),
     "gpt_gemm_prof_enable": ([i32], i32),
     "gpt_gemm_prof_collect": ([C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)], i32),
@@ -160,3 +161,20 @@ def dtype_code(dtype):
 
 def torch_dtype(code):
     return torch.bfloat16 if code == BF16 else torch.float32
+
+
+_gemm_ws = {}
+
+
+def ensure_gemm_workspace(device, nbytes=64 << 20):
+    """Registers (once per device) the scratch gpt_gemm_nt uses to contract small-batch problems in K spans; the buffer
+    lives as long as the process.  Users of the C-ABI alone call gpt_gemm_set_workspace themselves."""
+    import torch
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _gemm_ws:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", idx))
+        with torch.cuda.device(idx):
+            check(lib().gpt_gemm_set_workspace(ptr(buf), nbytes), "gpt_gemm_set_workspace")
+        _gemm_ws[idx] = buf
+    return _gemm_ws[idx]

@@ -236,6 +236,93 @@ int dispatch_ring(const GemmArgs<T>& g, int epi, hipStream_t s);
 // The 256 x 256 kernel runs one workgroup per CU, so a launch costs ceil(tiles / 256) full rounds however empty the
 // last one is (B = 320: 594 tiles -> 3 rounds at 77 %).  When the last round would be poorly filled, the row-tiles
 // that do not fill whole rounds are handed to the 128 x 128 kernel (2 workgroups per CU, a quarter of the work each).
+// ---- split-K through a caller-owned workspace -------------------------------------------------------------------------
+// Problems with few 256 x 256 tiles and a long K (sampling at B = 64: 42 tiles; training at B = 128: 78) leave most CUs
+// idle or fall to the slower 128 x 128 ring kernel.  With a workspace registered (gpt_gemm_set_workspace) the K range is
+// cut into spans: pass 1 = the 256 x 256 kernel, one workgroup per (span, tile), fp32 partial tiles stored plainly (float
+// atomics cost a CU ~50 ns per wave instruction: 51 us per tile, more than the tile's contraction); pass 2 = one
+// streaming kernel that sums the spans and applies the real epilogue.
+struct SplitWs {
+  float* ptr = nullptr;
+  size_t bytes = 0;
+};
+SplitWs g_split_ws_dev[32];   // per device: the registration applies to the device current at the call
+SplitWs& split_ws() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return g_split_ws_dev[dev & 31];
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs<T> g, const float* __restrict__ part, int nspan) {
+  const int groups = g.N >> 3;                       // 8 columns per thread
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)g.M * groups) return;
+  const int m = (int)(idx / groups), n = (int)(idx - (int64_t)m * groups) * 8;
+  const int64_t slab = (int64_t)g.M * g.N;
+  const float* p = part + (int64_t)m * g.N + n;
+  float4 v0 = reinterpret_cast<const float4*>(p)[0], v1 = reinterpret_cast<const float4*>(p)[1];
+  for (int sp = 1; sp < nspan; ++sp) {
+    const float4 a = reinterpret_cast<const float4*>(p + sp * slab)[0], b = reinterpret_cast<const float4*>(p + sp * slab)[1];
+    v0 = add4(v0, a);
+    v1 = add4(v1, b);
+  }
+  float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+  if (g.bias) {
+    b0 = reinterpret_cast<const float4*>(g.bias + n)[0];
+    b1 = reinterpret_cast<const float4*>(g.bias + n)[1];
+  }
+  EpiPre pre;
+  if constexpr (epi_reads<EPI>) epi_load8<T, EPI>(g, m, n, pre);
+  epi_store8<T, EPI>(g, m, n, add4(v0, b0), add4(v1, b1), pre);
+}
+
+template <typename T, int EPI>
+int launch_reduce(const GemmArgs<T>& g, const float* part, int nspan, hipStream_t s) {
+  const int64_t total = (int64_t)g.M * (g.N >> 3);
+  hipLaunchKernelGGL((splitk_reduce_kernel<T, EPI>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, part, nspan);
+  return gpt_launch_status("gpt_gemm_nt");
+}
+
+template <typename T>
+int dispatch_reduce(const GemmArgs<T>& g, int epi, const float* part, int nspan, hipStream_t s) {
+  switch (epi) {
+    case GPT_EPI_STORE: return launch_reduce<T, GPT_EPI_STORE>(g, part, nspan, s);
+    case GPT_EPI_GELU: return launch_reduce<T, GPT_EPI_GELU>(g, part, nspan, s);
+    case GPT_EPI_RESADD: return launch_reduce<T, GPT_EPI_RESADD>(g, part, nspan, s);
+    case GPT_EPI_STORE_F32: return launch_reduce<T, GPT_EPI_STORE_F32>(g, part, nspan, s);
+    case GPT_EPI_GELU_AUX: return launch_reduce<T, GPT_EPI_GELU_AUX>(g, part, nspan, s);
+    case GPT_EPI_DGELU: return launch_reduce<T, GPT_EPI_DGELU>(g, part, nspan, s);
+    case GPT_EPI_ACCUM_F32: return launch_reduce<T, GPT_EPI_ACCUM_F32>(g, part, nspan, s);
+  }
+  gpt_set_error("gpt_gemm_nt: unknown epilogue %d", epi);
+  return -1;
+}
+
+int n_cus();
+
+// spans for a problem of `tiles` 256 x 256 tiles and nk K-tiles: fill the CUs once, keep >= 16 K-tiles per span, fit the
+// workspace; 1 = do not split
+template <typename T>
+int pick_spans(const GemmArgs<T>& g, int tiles, int nk) {
+  static const bool enabled = [] {
+    const char* e = getenv("GPT_GEMM_SPLITK");   // 0 disables (A/B measurements)
+    return !e || atoi(e) != 0;
+  }();
+  const SplitWs& ws = split_ws();
+  if (!enabled || !ws.ptr || sizeof(T) != 2 || g.N % 8 != 0) return 1;
+  int sp = n_cus() / tiles;
+  // the partial tiles cost (spans + 1) x M x N x 4 bytes of traffic and a second launch: measured against the single-pass
+  // kernels the split wins from ~16 K-tiles (1024 of K) per span up (K = 6144: 70.7 -> 57.3 us at M = 1664, 129 -> 90 us
+  // at M = 3328) and loses below (K = 1536, 6 spans of 4: 24.5 -> 38.8 us)
+  if (sp > nk / 16) sp = nk / 16;
+  const size_t slab = (size_t)g.M * g.N * sizeof(float);
+  if ((size_t)sp * slab > ws.bytes) sp = (int)(ws.bytes / slab);
+  if (sp < 2) return 1;
+  const int per = (nk + sp - 1) / sp;              // K-tiles per span; drop the spans this rounding leaves empty
+  return (nk + per - 1) / per;
+}
+
 int n_cus() {
   static const int n_cu = [] {
     int dev = 0, n = 256;
@@ -289,6 +376,17 @@ template <typename T>
 int dispatch(const GemmArgs<T>& g, int epi, hipStream_t s) {
   const int tiles256 = ((g.M + 255) / 256) * ((g.N + 255) / 256);
   const bool k_ok = g.K % (128 / (int)sizeof(T)) == 0;   // the 256 x 256 kernel moves 128 bytes of K per row and K-tile
+  if (k_ok && tile_mode() == 0 && tiles256 < 128 && tiles256 * 2 <= n_cus()) {
+    const int sp = pick_spans(g, tiles256, g.K / (128 / (int)sizeof(T)));
+    if (sp > 1) {
+      if constexpr (sizeof(T) == 2) {
+        GemmArgs<T> part = g;                       // pass 1: raw fp32 partial tiles, [sp][M][N]
+        part.bias = nullptr; part.aux = nullptr; part.C = split_ws().ptr; part.ldc = g.N; part.ksplit = sp;
+        const int rc = gemm256_bf16(part, GPT_EPI_STORE_F32, 8, s);
+        return rc != 0 ? rc : dispatch_reduce<T>(g, epi, split_ws().ptr, sp, s);
+      }
+    }
+  }
   if (k_ok && (tile_mode() == 3 || (tile_mode() == 0 && tiles256 >= 128))) {
     int m_main = g.M;
     int rt = 8;
@@ -330,6 +428,12 @@ int dispatch_ring(const GemmArgs<T>& g, int epi, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int gpt_gemm_set_workspace(void* ptr, size_t bytes) {
+  GPT_REQUIRE((ptr == nullptr) == (bytes == 0) && ((uintptr_t)ptr % 16) == 0, "gpt_gemm_set_workspace: need a 16-byte aligned buffer (or NULL, 0)");
+  split_ws() = SplitWs{(float*)ptr, bytes};
+  return 0;
+}
 
 extern "C" int gpt_gemm_prof_enable(int on) {
   if (on && !g_prof.made) {

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
 
   STAMP_RT(4);
   STAMP(0);
-  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int nwg = gridDim.x / g.ksplit, span = blockIdx.x / nwg, bid = blockIdx.x - span * nwg;
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   const int tiles_n = (g.N + 255) / 256;
@@ -82,7 +82,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
   const int nk_tile = g.K / BK;
   const int fr = lane & 31, fh = lane >> 5;
 
-  const int tile = swz, nk = nk_tile;
+  const int nk_span = (nk_tile + g.ksplit - 1) / g.ksplit, kt0 = span * nk_span;
+  const int tile = swz, nk = min(nk_span, nk_tile - kt0);   // host: every span gets at least one K-tile
   // tile order inside an XCD's contiguous run: column groups of GROUP_N tiles, rows fastest across the group, so
   // the ~32 tiles an XCD works on at once form a ~4 x 8 block (A and W panels both re-used from its 4 MiB L2)
 #ifndef GPT_GROUP_N
@@ -105,10 +106,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
     for (int h = 0; h < 2; ++h) {
       int gm = m0 + (lr >> 6) * WROWS + min(h * 64 + (lr & 63), WROWS - 1);
       gm = gm < g.M ? gm : g.M - 1;
-      srcA[h][p] = g.A + (int64_t)gm * g.lda + lc * EPC;
+      srcA[h][p] = g.A + (int64_t)gm * g.lda + lc * EPC + (int64_t)kt0 * BK;
       int gn = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
       gn = gn < g.N ? gn : g.N - 1;
-      srcW[h][p] = g.W + (int64_t)gn * g.ldw + lc * EPC;
+      srcW[h][p] = g.W + (int64_t)gn * g.ldw + lc * EPC + (int64_t)kt0 * BK;
     }
   }
   auto dma = [&](const T* const (&src)[2], int kt, int slot) {
@@ -283,7 +284,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
         for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + 4 * fh) * PATCH_PITCH + j * 32 + fr] = acc[step][j][e];
     }
   };
-  epilogue_wave<T, EPI, 4, WROWS>(g, to_patch, patch, m0 + wr * WROWS, n0 + wc * 64, lane);
+  GemmArgs<T> ge = g;
+  if (g.ksplit > 1) ge.C = (float*)g.C + (int64_t)span * g.M * g.ldc;   // this span's slab of the workspace (STORE_F32)
+  epilogue_wave<T, EPI, 4, WROWS>(ge, to_patch, patch, m0 + wr * WROWS, n0 + wc * 64, lane);
 #ifdef GPT_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -304,7 +307,7 @@ int launch256(const GemmArgs<T>& g, hipStream_t s) {
     attr_set = true;
   }
   const int tiles = ((g.M + 32 * RT - 1) / (32 * RT)) * ((g.N + 255) / 256);
-  const int grid = tiles;
+  const int grid = tiles * g.ksplit;
   const bool rec = g_prof.on && g_prof.n < GemmProf::CAP;
   if (rec) (void)hipEventRecord(g_prof.ev[g_prof.n][0], s);
   hipLaunchKernelGGL((gemm256_kernel<T, EPI, RT>), dim3(grid), dim3(512), LDS_BYTES, s, g);

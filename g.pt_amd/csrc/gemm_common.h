@@ -16,6 +16,9 @@ struct GemmArgs {
   void* aux;
   int64_t lda, ldw, ldc, ldaux;
   int M, N, K;
+  // K spans (gemm256 only, GPT_EPI_STORE_F32 into a workspace): workgroup (span, tile) contracts K-tiles
+  // [span * ceil(nk / ksplit), ...) and stores its partial tile at C + span * M * ldc
+  int ksplit = 1;
 };
 
 template <typename T>

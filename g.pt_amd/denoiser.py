@@ -199,6 +199,7 @@ class _Engine:
         self.keep = []
         self.cmodel = None
         self.ws = {}
+        L.ensure_gemm_workspace(device)
 
     # ---- weights
     def _signature(self):

@@ -17,6 +17,7 @@
  */
 #ifndef GPT_HIP_H
 #define GPT_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -46,6 +47,13 @@ int gpt_abi_version(void);
 int gpt_gemm_nt(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                 void* C, int64_t ldc, void* aux, int64_t ldaux, int M, int N, int K, int epilogue,
                 void* stream);
+
+/* Optional scratch for gpt_gemm_nt (bf16): with a device buffer registered, problems of few 256 x 256 output tiles and a
+ * long K (small batches) are contracted in K spans - fp32 partial tiles into this buffer, then one streaming pass that
+ * sums them and applies the epilogue - instead of leaving most CUs idle.  The buffer stays the caller's (the library
+ * never allocates); it must outlive the calls, and calls that use it must not overlap on different streams.
+ * 64 MiB covers the G.pt shapes.  (NULL, 0) unregisters.  No counterpart in the reference (an ATen/cuBLAS internal). */
+int gpt_gemm_set_workspace(void* ptr, size_t bytes);
 
 /* C[I, J] (+)= P[R, I]^T . Q[R, J]: bf16 operands contracted over their ROW index, fp32 output (accumulate != 0:
  * C += ...).  The weight gradient dW = dY^T . X that autograd derives for every nn.Linear of the trunk

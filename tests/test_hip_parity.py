@@ -87,6 +87,63 @@ def test_gemm_epilogues(dtype, tol, M, N, K):
     assert rel_err(out.float().cpu(), torch.nn.functional.gelu(ref)) < tol
 
 
+@pytest.mark.parametrize("M,N,K", [(1664, 1536, 6144), (1700, 1528, 6464), (3328, 1536, 4608), (520, 264, 2048)])
+def test_gemm_split_k_workspace(M, N, K):
+    """bf16 problems of few 256 x 256 tiles and a long K go through K spans + a reduce pass once a workspace is registered
+    (gpt_gemm_set_workspace): every epilogue against fp64, ragged M / N / K-span counts included, and the output after
+    un-registering (single-pass kernels) must agree to bf16 rounding."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
+    bias, R = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    Ad, Wd = A.to(DEV).bfloat16(), W.to(DEV).bfloat16()
+    ref = Ad.float().cpu().double() @ Wd.float().cpu().double().t() + bias.double()
+    lib, bias_d, tol = L.lib(), bias.to(DEV), 1e-2
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+
+    def run(epi, Cbuf, aux=None, ldaux=0, use_bias=True):
+        L.check(lib.gpt_gemm_nt(L.BF16, L.ptr(Ad), K, L.ptr(Wd), K, L.ptr(bias_d) if use_bias else None, L.ptr(Cbuf), N,
+                                L.ptr(aux), ldaux, M, N, K, epi, L.stream()), "gemm")
+        torch.cuda.synchronize()
+
+    gelu = torch.nn.functional.gelu
+    try:
+        L.check(lib.gpt_gemm_set_workspace(L.ptr(ws), ws.numel()), "ws")
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        run(L.EPI_STORE, out)
+        split = out.clone()
+        assert rel_err(out.float().cpu(), ref) < tol
+        run(L.EPI_GELU, out)
+        assert rel_err(out.float().cpu(), gelu(ref)) < tol
+        acc = R.to(DEV).clone()
+        run(L.EPI_RESADD, acc)
+        assert rel_err(acc.cpu(), R.double() + ref) < 1e-4          # fp32 partials, fp32 output
+        acc2, Rd = torch.empty(M, N, device=DEV), R.to(DEV)
+        run(L.EPI_RESADD, acc2, aux=Rd, ldaux=N)
+        assert torch.equal(acc2, acc)
+        f32o = torch.empty(M, N, device=DEV)
+        run(L.EPI_STORE_F32, f32o, use_bias=False)
+        assert rel_err(f32o.cpu(), ref - bias.double()) < 1e-4
+        accum = R.to(DEV).clone()
+        run(L.EPI_ACCUM_F32, accum, use_bias=False)
+        assert rel_err(accum.cpu(), R.double() + ref - bias.double()) < 1e-4
+        pre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        run(L.EPI_GELU_AUX, out, aux=pre, ldaux=N)
+        assert torch.equal(pre, split)
+        assert rel_err(out.float().cpu(), gelu(ref)) < tol
+        z = (torch.randn(M, N, generator=g) * 1.5).to(DEV).bfloat16()
+        run(L.EPI_DGELU, out, aux=z, ldaux=N)
+        zd = z.float().cpu().double().requires_grad_(True)
+        gelu(zd).sum().backward()
+        assert rel_err(out.float().cpu(), ref * zd.grad) < tol
+    finally:
+        L.check(lib.gpt_gemm_set_workspace(None, 0), "ws")
+    single = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    run(L.EPI_STORE, single)
+    d = (single.float() - split.float()).abs()
+    assert bool((d <= split.float().abs() * 2.0 ** -7 + 1e-5).all()), float(d.max())
+    L._gemm_ws.pop(torch.device(DEV).index, None)     # the engines' registration was replaced above: let them renew it
+
+
 def test_gemm_gelu_bf16_range():
     """bf16 GELU epilogue (x * sigmoid(fitted odd polynomial)) against the exact erf GELU over [-30, 30], outliers included:
     error <= one bf16 rounding of the result + 2.6e-5 (the fit's bound, gemm_common.h)."""

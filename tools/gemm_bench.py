@@ -32,6 +32,7 @@ def main():
             f = spec.split(":")
             shapes.append((f[0], int(f[1]), int(f[2]), int(f[3]), int(f[4]) if len(f) > 4 else L.EPI_STORE))
     lib = L.lib()
+    L.ensure_gemm_workspace(dev)          # GPT_GEMM_SPLITK=0 in the environment keeps the single-pass kernels
     bufs = []
     for name, m, n, k, epi in shapes:
         A = torch.randn(m, k, device=dev).to(td)
