@@ -3,7 +3,8 @@
 `synth` / `create_thresholding_fn` keep the signatures of Gpt/vis.py:190-252.  `mlp_test_losses` replaces
 moduleify + batch_test_fn + test_epoch (vis.py:398-413, 539-570; data_gen/train_mnist.py:324-332) for the MNIST MLP:
 all B sampled nets are scored in two launches (one exact-fp32 MFMA GEMM for fc1 of every net, one fused head kernel)
-instead of B Python iterations."""
+instead of B Python iterations.  `cnn_test_losses` does the same for the CIFAR-10 ConvNet (data_gen/train_cifar10.py:53-68,
+426-434) in one fused kernel (both convolutions, pooling, fc and the loss; conv2 on fp32 MFMAs)."""
 import torch
 
 from . import _lib as L
@@ -72,4 +73,33 @@ def mlp_test_losses(nets, images, labels, hidden=10, classes=10):
     err = torch.empty(B, device=dev)
     L.check(lib.gpt_mlp_head(L.ptr(H), np_, L.ptr(nets), D, off_b1, off_w2, off_b2, L.ptr(labels), L.ptr(loss), L.ptr(err),
                              B, hidden, classes, n_img, L.stream()), "gpt_mlp_head")
+    return loss, err
+
+
+CNN_D = 5370          # conv1.weight (16,3,3,3) | conv2.weight (32,16,3,3) | fc.weight (10,32) | fc.bias (10)
+
+
+@torch.no_grad()
+def cnn_test_losses(nets, images, labels):
+    """(loss [B], err% [B]): mean cross-entropy and top-1 error of B flat CIFAR-10 ConvNet parameter vectors (state_dict
+    order, train_cifar10.py:55-60) on `images` [N, 3, 32, 32] (already colour-normalised, :158-160) / `labels` [N]."""
+    lib = L.lib()
+    if not nets.is_cuda:
+        raise L.GptHipError("cnn_test_losses: the HIP path needs GPU tensors; there is no CPU fallback")
+    dev = nets.device
+    assert nets.dim() == 2 and nets.shape[1] == CNN_D, f"expected (B, {CNN_D}) parameter vectors"
+    assert images.dim() == 4 and tuple(images.shape[1:]) == (3, 32, 32), "expected (N, 3, 32, 32) images"
+    x = images.to(dev, torch.float32).contiguous()
+    nets = nets.float().contiguous()
+    labels = labels.to(dev, torch.long).contiguous()
+    B, n_img = nets.shape[0], x.shape[0]
+    assert labels.numel() == n_img and n_img > 0
+    assert int(labels.min()) >= 0 and int(labels.max()) < 10
+    groups = (B + 3) // 4                     # one workgroup = 4 nets x one chunk of the images
+    chunks = max(1, min((n_img + 7) // 8, (1024 + groups - 1) // groups))
+    partial = torch.empty(B, chunks, 2, device=dev)
+    loss = torch.empty(B, device=dev)
+    err = torch.empty(B, device=dev)
+    L.check(lib.gpt_cnn_eval(L.ptr(x), L.ptr(labels), L.ptr(nets), CNN_D, L.ptr(partial), chunks, L.ptr(loss), L.ptr(err),
+                             B, n_img, L.stream()), "gpt_cnn_eval")
     return loss, err

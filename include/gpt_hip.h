@@ -323,6 +323,15 @@ int gpt_ddim_sample_loop(const gpt_model_t* m, const gpt_workspace_t* ws, float*
 int gpt_mlp_head(const float* H, int64_t ldh, const float* nets, int64_t net_stride, int off_b1, int off_w2, int off_b2,
                  const int64_t* labels, float* loss, float* err, int B, int hidden, int classes, int n_img, void* stream);
 
+/* Quality metric for the CIFAR-10 ConvNet (replaces moduleify + the per-net loop of batch_test_fn, Gpt/vis.py:398-413,
+ * 539-570, around data_gen/train_cifar10.py:53-68 and test_epoch :426-434): mean cross-entropy loss[b] and top-1 error
+ * err[b] (percent) of B flat parameter vectors nets[b * net_stride + ...] = conv1.weight [16,3,3,3] | conv2.weight
+ * [32,16,3,3] | fc.weight [10,32] | fc.bias [10] on images [n_img,3,32,32] fp32 / labels int64 [n_img], in one fused
+ * kernel.  The images are cut into `chunks` ranges (grid = ceil(B/4) x chunks); partial = caller scratch of
+ * B * chunks * 2 floats. */
+int gpt_cnn_eval(const float* images, const int64_t* labels, const float* nets, int64_t net_stride, float* partial, int chunks,
+                 float* loss, float* err, int B, int n_img, void* stream);
+
 /* ---- optimizer step on one flat fp32 parameter arena (training-step harness, main.py:66-74) ----------------------
  * A segment is one named parameter: `count` elements at element offset `start` of the arenas (starts are multiples
  * of 4 elements; the gap up to the next start is zero padding).  decay: 1 = AdamW weight-decay group (Linear

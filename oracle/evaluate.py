@@ -2,7 +2,8 @@
 
 moduleify (Gpt/vis.py:539-570) loads a flat parameter vector into the task net in state_dict order
 (fc1.weight, fc1.bias, fc2.weight, fc2.bias for data_gen/train_mnist.py:58-71) and batch_test_fn (vis.py:398-413) calls
-the task's test_epoch (train_mnist.py:324-332) once per net.  Pinned by tests/golden/g10_mlp_eval.npz."""
+the task's test_epoch (train_mnist.py:324-332) once per net.  Pinned by tests/golden/g10_mlp_eval.npz.
+The CIFAR-10 ConvNet (data_gen/train_cifar10.py:53-68, test_epoch :426-434) likewise; pinned by g12_cnn_eval.npz."""
 import torch
 import torch.nn.functional as F
 
@@ -26,6 +27,31 @@ def mlp_eval(nets, imgs, labels, hidden=10, classes=10):
         w1, b1 = v[:off_b1].view(hidden, in_dim), v[off_b1:off_w2]
         w2, b2 = v[off_w2:off_b2].view(classes, hidden), v[off_b2:D]
         logits = F.linear(F.relu(F.linear(x, w1, b1)), w2, b2)
+        losses.append(F.cross_entropy(logits, labels, reduction="none").mean())
+        errs.append((logits.argmax(1) != labels).float().mean() * 100)
+    return torch.stack(losses), torch.stack(errs)
+
+
+CNN_SHAPES = (("conv1.weight", (16, 3, 3, 3)), ("conv2.weight", (32, 16, 3, 3)), ("fc.weight", (10, 32)), ("fc.bias", (10,)))
+
+
+def cnn_eval(nets, imgs, labels):
+    """(loss [B], err% [B]) of B flat CIFAR-10 ConvNet vectors (state_dict order of train_cifar10.py:55-60) on imgs
+    [N, 3, 32, 32]: relu(conv1 s2 p1) -> relu(conv2 s1 p1) -> global average pool -> fc (train_cifar10.py:62-68)."""
+    assert nets.shape[1] == 5370
+    x = imgs.float()
+    losses, errs = [], []
+    for v in nets:
+        w, off = {}, 0
+        for name, shape in CNN_SHAPES:
+            n = 1
+            for d in shape:
+                n *= d
+            w[name] = v[off:off + n].view(shape)
+            off += n
+        h = F.relu(F.conv2d(x, w["conv1.weight"], stride=2, padding=1))
+        h = F.relu(F.conv2d(h, w["conv2.weight"], stride=1, padding=1))
+        logits = F.linear(h.mean(dim=(2, 3)), w["fc.weight"], w["fc.bias"])
         losses.append(F.cross_entropy(logits, labels, reduction="none").mean())
         errs.append((logits.argmax(1) != labels).float().mean() * 100)
     return torch.stack(losses), torch.stack(errs)

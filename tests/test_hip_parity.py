@@ -48,7 +48,9 @@ def build(case, dtype="fp32", seed=0):
                                    (77, 136, 256),
                                    # the 256 x 256 kernel: 224-row tiles with a ragged last row tile (8320 = 37.1 x 224),
                                    # 256-row tiles filling whole rounds, and a row tail handed to the ring kernels
-                                   (8320, 1536, 256), (4096, 4096, 128), (8320, 6144, 128)])
+                                   (8320, 1536, 256), (4096, 4096, 128), (8320, 6144, 128),
+                                   # 128-row tiles of the same kernel (few tiles: one per CU)
+                                   (1664, 4608, 192)])
 def test_gemm_epilogues(dtype, tol, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
     A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
@@ -475,6 +477,36 @@ def test_batched_mlp_eval_golden_and_oracle(golden):
     np.testing.assert_allclose(err.cpu().numpy(), want_err.numpy(), rtol=0, atol=1e-4)
     with pytest.raises(L.GptHipError):
         gpt_amd.mlp_test_losses(nets, imgs, labels)                 # CPU tensors: no fallback
+
+
+def test_batched_cnn_eval_golden_and_oracle(golden):
+    """All sampled CIFAR-10 ConvNets scored by one fused kernel (conv1 VALU, conv2 fp32 MFMA, pool, fc, loss): fp32
+    throughout, summation order differs from ATen's convolutions -> rtol 2e-5 on the mean loss; the error count is exact
+    unless two logits tie to within rounding (none do on these seeds)."""
+    from oracle import evaluate as oe
+    g = golden("g12_cnn_eval")
+    nets, imgs, labels = (torch.from_numpy(g[k]) for k in ("nets", "imgs", "labels"))
+    loss, err = gpt_amd.cnn_test_losses(nets.to(DEV), imgs.to(DEV), labels.to(DEV))
+    np.testing.assert_allclose(loss.cpu().numpy(), g["loss"], rtol=2e-5)
+    np.testing.assert_allclose(err.cpu().numpy(), g["err"], rtol=0, atol=1e-4)
+    # more nets than one workgroup round, a ragged last group (B % 4 = 1), an image count that the chunks do not divide,
+    # weights at trained-net scale so that the ReLUs and the logits are far from degenerate
+    gen = torch.Generator().manual_seed(78)
+    nets = torch.randn(1029, 5370, generator=gen) * 0.3
+    imgs = torch.randn(203, 3, 32, 32, generator=gen)
+    labels = torch.randint(0, 10, (203,), generator=gen)
+    loss, err = gpt_amd.cnn_test_losses(nets.to(DEV), imgs.to(DEV), labels.to(DEV))
+    sel = torch.tensor([0, 1, 2, 3, 4, 515, 1024, 1027, 1028])
+    want_loss, want_err = oe.cnn_eval(nets[sel], imgs, labels)
+    np.testing.assert_allclose(loss.cpu()[sel].numpy(), want_loss.numpy(), rtol=2e-5)
+    np.testing.assert_allclose(err.cpu()[sel].numpy(), want_err.numpy(), rtol=0, atol=1e-4)
+    # one image, one net
+    l1, e1 = gpt_amd.cnn_test_losses(nets[:1].to(DEV), imgs[:1].to(DEV), labels[:1].to(DEV))
+    w1, we1 = oe.cnn_eval(nets[:1], imgs[:1], labels[:1])
+    np.testing.assert_allclose(l1.cpu().numpy(), w1.numpy(), rtol=2e-5)
+    assert float(e1) == float(we1)
+    with pytest.raises(L.GptHipError):
+        gpt_amd.cnn_test_losses(nets, imgs, labels)                 # CPU tensors: no fallback
 
 
 def test_synth_matches_p_sample_loop_with_static_thresholding(golden):

@@ -150,3 +150,12 @@ def test_g10_mlp_eval(golden):
     loss, err = oe.mlp_eval(torch.from_numpy(g["nets"]), torch.from_numpy(g["imgs"]), torch.from_numpy(g["labels"]))
     np.testing.assert_allclose(loss.numpy(), g["loss"], rtol=1e-5)
     np.testing.assert_allclose(err.numpy(), g["err"], rtol=0, atol=1e-4)
+
+
+def test_g12_cnn_eval(golden):
+    """The oracle's functional ConvNet evaluation against the reference's ConvNet + moduleify + cross_entropy."""
+    from oracle import evaluate as oe
+    g = golden("g12_cnn_eval")
+    loss, err = oe.cnn_eval(torch.from_numpy(g["nets"]), torch.from_numpy(g["imgs"]), torch.from_numpy(g["labels"]))
+    np.testing.assert_allclose(loss.numpy(), g["loss"], rtol=1e-5)
+    np.testing.assert_allclose(err.numpy(), g["err"], rtol=0, atol=1e-4)

@@ -323,8 +323,36 @@ def g10_mlp_eval():
          loss=np.array(losses), err=np.array(errs))
 
 
+# ------------------------------------------------------------------ G12: functional ConvNet evaluation
+def g12_cnn_eval():
+    import data_gen.train_cifar10 as tc
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(52)
+    nets = torch.randn(6, 5370, generator=g) * 0.15
+    imgs = torch.randn(96, 3, 32, 32, generator=g)
+    labels = torch.randint(0, 10, (96,), generator=g)
+    losses, errs = [], []
+    for v in nets:
+        net = tc.ConvNet()
+        off, new = 0, {}
+        for k, p in net.state_dict().items():                     # moduleify (Gpt/vis.py:539-570)
+            new[k] = v[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        assert off == 5370
+        net.load_state_dict(new)
+        with torch.no_grad():
+            logits = net.eval()(imgs)
+            losses.append(F.cross_entropy(logits, labels, reduction="none").mean().item())   # test_epoch (:426-434)
+            errs.append((logits.argmax(1) != labels).float().mean().item() * 100)
+    save("g12_cnn_eval", nets=nets.numpy(), imgs=imgs.numpy(), labels=labels.numpy(),
+         loss=np.array(losses), err=np.array(errs))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g12":          # only the ConvNet fixture (added after G1-G11)
+        g12_cnn_eval()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g11":          # only the DDIM fixtures (added after G1-G10)
         g11_ddim("mnist_small", "ddim25", "ddim25_eta0", 0.0)
         g11_ddim("mnist_small", "50", "r50_eta05", 0.5)
@@ -349,3 +377,4 @@ if __name__ == "__main__":
     g11_ddim("mnist_small", "ddim25", "ddim25_eta0", 0.0)
     g11_ddim("mnist_small", "50", "r50_eta05", 0.5)
     g11_ddim("cifar_small", "ddim25", "ddim25_eta1_eps_clip", 1.0, predict_xstart=False, clip=True)
+    g12_cnn_eval()
