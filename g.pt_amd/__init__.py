@@ -13,3 +13,4 @@ from .dp import (is_main_proc, scaled_all_reduce, get_rank, get_world_size, sync
                  rank0_to_all)
 from . import permute  # noqa: F401
 from .evaluate import synth, create_thresholding_fn, mlp_test_losses, cnn_test_losses  # noqa: F401,E402
+from .data import CheckpointStore, write_flat_db  # noqa: F401,E402

@@ -65,7 +65,34 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs g, const int64_t
   }
 }
 
+// Training-pair fetch from a checkpoint store resident in HBM: row gather + parameter normalisation + permutation
+// augmentation in one pass (ParameterDataset.__getitem__, Gpt/data/dataset_lmdb.py:218-225: database[...] -> normalize ->
+// aug_fn on both checkpoints of the pair).  HBM-bound: 16 bytes per element and pair (+ 8 of index when augmenting).
+__global__ __launch_bounds__(256) void pair_gather_kernel(const float* __restrict__ store, int64_t ld, const int64_t* __restrict__ row0,
+                                                          const int64_t* __restrict__ row1, const int64_t* __restrict__ index,
+                                                          float scale, float* __restrict__ out0, float* __restrict__ out1, int D) {
+  const int s = blockIdx.y;
+  const float* a = store + row0[s] * ld;
+  const float* b = store + row1[s] * ld;
+  const int64_t* idx = index ? index + (int64_t)s * D : nullptr;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < D; i += gridDim.x * blockDim.x) {
+    const int64_t j = idx ? idx[i] : i;
+    out0[(int64_t)s * D + i] = a[j] * scale;
+    out1[(int64_t)s * D + i] = b[j] * scale;
+  }
+}
+
 }  // namespace
+
+extern "C" int gpt_pair_gather(const float* store, int64_t ld, int64_t n_rows, const int64_t* row0, const int64_t* row1,
+                               const int64_t* index, float scale, float* out0, float* out1, int n_samples, int D, void* stream) {
+  GPT_REQUIRE(store && row0 && row1 && out0 && out1 && n_samples > 0 && D > 0 && ld >= D && n_rows > 0,
+              "gpt_pair_gather: bad arguments (need ld >= D, n_rows > 0)");
+  GPT_REQUIRE(n_samples <= 65535, "gpt_pair_gather: at most 65535 pairs per call");
+  const dim3 grid((D + 255) / 256 > 16 ? 16 : (D + 255) / 256, n_samples);
+  hipLaunchKernelGGL(pair_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, store, ld, row0, row1, index, scale, out0, out1, D);
+  return gpt_launch_status("gpt_pair_gather");
+}
 
 extern "C" int gpt_perm_index_mlp(const int32_t* perms, int64_t* index, int n_samples, int n_in, int hidden, int n_out,
                                   void* stream) {

@@ -202,6 +202,14 @@ int gpt_perm_index_cnn(const int32_t* perms, int64_t* index, int n_samples, int 
 int gpt_perm_gather(const float* const* host_src, float* const* host_dst, int n_nets, const int64_t* index,
                     int n_samples, int D, void* stream);
 
+/* Training-pair fetch from a checkpoint store held in HBM (ParameterDataset.__getitem__, Gpt/data/dataset_lmdb.py:218-225:
+ * database[key_0], database[key_1] -> normalize (Gpt/data/normalization.py:23-25) -> aug_fn on both):
+ *   out0[s, i] = store[row0[s] * ld + j] * scale,  out1[s, i] = store[row1[s] * ld + j] * scale,  j = index ? index[s, i] : i
+ * store: fp32 [n_rows, ld] (one checkpoint per row), row0/row1: int64 device [n_samples] (the caller keeps them < n_rows),
+ * index: int64 device [n_samples, D] from gpt_perm_index_* or NULL, scale = openai_coeff (1 for the identity normaliser). */
+int gpt_pair_gather(const float* store, int64_t ld, int64_t n_rows, const int64_t* row0, const int64_t* row1,
+                    const int64_t* index, float scale, float* out0, float* out1, int n_samples, int D, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Whole-path entry points: one host call launches every kernel of a denoiser forward / of the whole
  * reverse-diffusion loop on `stream` (no host synchronisation, no allocation), so the Python caller pays

@@ -88,3 +88,48 @@ def block_case(d, seed=5):
             sd[n] = torch.randn(s, generator=g) * 0.1 + (1.0 if n in ("ln1.weight", "ln2.weight") else 0.0)
     xin = torch.randn(2, 26, d, generator=g)
     return sd, xin
+
+
+# ------------------------------------------------------------------ synthetic checkpoint datasets (fixture g13)
+PAIR_CASES = {
+    "mnist": dict(dataset_name="mnist_loss", D=7960, sizes=[7840, 10, 100, 10], train_metric="avg_test_loss",
+                  dirs=["r00_r01_r02", "r03", "r04", "r05", "r06"], n_ckpt=[7, 5, 9, 6, 8, 4, 6], openai_coeff=4.185,
+                  num_test_runs=2, augment=True, items=[0, 5, 3, 12, 7, 1, 4, 9], seed=123),
+    "cifar": dict(dataset_name="cifar10_error", D=5370, sizes=[432, 4608, 320, 10], train_metric="avg_test_err",
+                  dirs=["a0", "a1_a2", "a3"], n_ckpt=[6, 6, 5, 7], openai_coeff=1.646,
+                  num_test_runs=1, augment=True, items=[2, 0, 1, 5, 4, 3], seed=321),
+}
+
+
+def make_pair_dataset(root, case):
+    """Writes runs.json files under root/<dir>/ and returns {dir path: {key: fp32 tensor}} (values regenerated from seeds:
+    the fixture holds no parameter data, only what the reference returned for it)."""
+    import json
+    import os
+    c = PAIR_CASES[case]
+    g = torch.Generator().manual_seed(c["seed"])
+    dbs, r = {}, 0
+    for d in c["dirs"]:
+        path = os.path.join(root, d)
+        os.makedirs(path, exist_ok=True)
+        db, fused = {}, {}
+        for run in d.split("_"):
+            n = c["n_ckpt"][r]
+            ck, series, lo, hi = {}, [], 1e9, -1e9
+            for i in range(n):
+                key = f"{run}/ep{i:03d}_it{i * 50:05d}.pt"
+                v = torch.randn(c["D"], generator=g) * 0.25
+                db[key] = v
+                db[key + "_arch"] = torch.tensor(c["sizes"], dtype=torch.float32)
+                val = float(torch.rand((), generator=g).double() * 2.0 + 0.05)
+                ck[key] = {c["train_metric"]: val}
+                series.append(val)
+                lo, hi = min(lo, float(v.min())), max(hi, float(v.max()))
+            opt_key = ("optimal_" + c["train_metric"]).replace("_avg", "")
+            fused[run] = {"checkpoints": ck, "metadata": {c["train_metric"]: series, opt_key: min(series),
+                                                          "min_parameter_val": lo, "max_parameter_val": hi}}
+            r += 1
+        with open(os.path.join(path, "runs.json"), "w") as f:
+            json.dump(fused if len(fused) > 1 else next(iter(fused.values())), f)
+        dbs[path] = db
+    return dbs

@@ -509,6 +509,70 @@ def test_batched_cnn_eval_golden_and_oracle(golden):
         gpt_amd.cnn_test_losses(nets, imgs, labels)                 # CPU tensors: no fallback
 
 
+@pytest.mark.parametrize("case", ["mnist", "cifar"])
+def test_checkpoint_store_pairs_golden_and_oracle(golden, tmp_path, case):
+    """CheckpointStore (split resident in HBM, one gather launch per batch) against the reference's ParameterDataset
+    fixture: BIT-EXACT parameters (row gather, fp32 multiply by the coefficient, integer permutation map), identical keys,
+    spacings and metrics for the same RNG state; then a larger batch and the un-augmented path against the oracle."""
+    from gpt_amd import data as gdata
+    from oracle import data as odata
+    from tests.cases import PAIR_CASES, make_pair_dataset
+    g, c = golden("g13_pairs"), PAIR_CASES[case]
+    dbs = make_pair_dataset(str(tmp_path), case)
+    for path, db in dbs.items():
+        gdata.write_flat_db(path, db.items())          # beside runs.json, as the converter leaves it
+    m = c["train_metric"]
+    for split in ("train", "test"):
+        ds = gdata.CheckpointStore(str(tmp_path), c["dataset_name"], split=split, num_test_runs=c["num_test_runs"],
+                                   train_metric=m, openai_coeff=c["openai_coeff"], target_epoch_size=1000,
+                                   permute_augment=True, device=DEV)
+        tag = f"{case}_{split}"
+        assert list(g[f"{tag}_runs"]) == ds.runs and list(g[f"{tag}_sizes"]) == ds.parameter_sizes
+        np.testing.assert_array_equal(g[f"{tag}_scalars"], np.array([ds.min_val, ds.max_val, ds.optimal_test_loss,
+                                                                     float(len(ds)), *ds.get_range(normalize=True)]))
+        torch.manual_seed(c["seed"] + 1)
+        b = ds.get_batch(c["items"])
+        assert b["checkpoint_key_0"] == list(g[f"{tag}_key0"]) and b["checkpoint_key_1"] == list(g[f"{tag}_key1"])
+        assert b["run_name"] == list(g[f"{tag}_run"])
+        np.testing.assert_array_equal(b["step_spacing"].numpy(), g[f"{tag}_spacing"])
+        assert b[f"{m}_0"].dtype == torch.float64
+        np.testing.assert_array_equal(b[f"{m}_0"].numpy(), g[f"{tag}_m0"])
+        np.testing.assert_array_equal(b[f"{m}_1"].numpy(), g[f"{tag}_m1"])
+        np.testing.assert_array_equal(b["parameters_0"].cpu().numpy()[:, ::7], g[f"{tag}_p0"])
+        np.testing.assert_array_equal(b["parameters_1"].cpu().numpy()[:, ::7], g[f"{tag}_p1"])
+        net = ds.get_run_network(len(ds.runs) - 1, iter=2, normalize=True, augment=False)
+        np.testing.assert_array_equal(net.cpu().numpy()[::7], g[f"{tag}_net"])
+        # the same items one at a time consume the RNG identically
+        torch.manual_seed(c["seed"] + 1)
+        one = [ds[i] for i in c["items"][:3]]
+        for k, it in enumerate(one):
+            assert torch.equal(it["parameters_1"], b["parameters_1"][k]) and it["checkpoint_key_0"] == b["checkpoint_key_0"][k]
+    # a batch of 300 indices, no augmentation, explicit generator, identity normaliser: against the oracle
+    ds = gdata.CheckpointStore(str(tmp_path), c["dataset_name"], split="train", num_test_runs=c["num_test_runs"], train_metric=m,
+                               normalizer_name="none", target_epoch_size=1000, device=DEV, min_step_spacing=2,
+                               max_step_spacing=3, generator=torch.Generator().manual_seed(5))
+    ref = odata.RefPairDataset(str(tmp_path), lambda p: dbs[p], split="train", num_test_runs=c["num_test_runs"],
+                               train_metric=m, normalizer_name="none", target_epoch_size=1000, min_step_spacing=2,
+                               max_step_spacing=3)
+    ref.generator = torch.Generator().manual_seed(5)
+    idx = torch.randint(0, len(ds), (300,), generator=torch.Generator().manual_seed(6)).tolist()
+    b = ds.get_batch(idx)
+    want = [ref[i] for i in idx]
+    assert torch.equal(b["parameters_0"].cpu(), torch.stack([w["parameters_0"] for w in want]))
+    assert torch.equal(b["parameters_1"].cpu(), torch.stack([w["parameters_1"] for w in want]))
+    assert b["checkpoint_key_1"] == [w["checkpoint_key_1"] for w in want]
+    assert ds.get_range(normalize=True) == ref.get_range()
+    # one epoch of batches for two ranks: disjoint shares of one permutation, whole batches only
+    seen = []
+    for rank in (0, 1):
+        n = 0
+        for bb in ds.batches(64, seed=3, rank=rank, world=2):
+            assert bb["parameters_0"].shape == (64, ds.D)
+            n += 1
+        seen.append(n)
+    assert seen[0] == seen[1] == (len(ds) // 2) // 64
+
+
 def test_synth_matches_p_sample_loop_with_static_thresholding(golden):
     """synth (Gpt/vis.py:210-252) = p_sample_loop with the harness' model_kwargs and the 'static' denoised_fn."""
     m, plan, sd = build("mnist_small", "fp32")

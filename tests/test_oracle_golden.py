@@ -159,3 +159,45 @@ def test_g12_cnn_eval(golden):
     loss, err = oe.cnn_eval(torch.from_numpy(g["nets"]), torch.from_numpy(g["imgs"]), torch.from_numpy(g["labels"]))
     np.testing.assert_allclose(loss.numpy(), g["loss"], rtol=1e-5)
     np.testing.assert_allclose(err.numpy(), g["err"], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("case", ["mnist", "cifar"])
+@pytest.mark.parametrize("split", ["train", "test"])
+def test_g13_pair_dataset(golden, tmp_path, case, split):
+    """The oracle's checkpoint-pair dataset against the reference's ParameterDataset over the same synthetic runs: split,
+    metadata reductions, the per-item RNG order (spacing, first index, permutation), normalisation and augmentation."""
+    from oracle import data as odata
+    from tests.cases import PAIR_CASES, make_pair_dataset
+    g, c = golden("g13_pairs"), PAIR_CASES[case]
+    dbs = make_pair_dataset(str(tmp_path), case)
+    ds = odata.RefPairDataset(str(tmp_path), lambda p: dbs[p], split=split, num_test_runs=c["num_test_runs"],
+                              train_metric=c["train_metric"], openai_coeff=c["openai_coeff"], target_epoch_size=1000,
+                              augment="mlp" if case == "mnist" else "cnn")
+    tag, m = f"{case}_{split}", c["train_metric"]
+    assert list(g[f"{tag}_runs"]) == ds.runs and list(g[f"{tag}_sizes"]) == ds.parameter_sizes
+    np.testing.assert_array_equal(g[f"{tag}_scalars"], np.array([ds.min_val, ds.max_val, ds.optimal_test_loss,
+                                                                 float(ds.epoch_size), *ds.get_range()]))
+    torch.manual_seed(c["seed"] + 1)
+    items = [ds[i] for i in c["items"]]
+    assert [it["checkpoint_key_0"] for it in items] == list(g[f"{tag}_key0"])
+    assert [it["checkpoint_key_1"] for it in items] == list(g[f"{tag}_key1"])
+    assert [it["run_name"] for it in items] == list(g[f"{tag}_run"])
+    np.testing.assert_array_equal([it["step_spacing"] for it in items], g[f"{tag}_spacing"])
+    np.testing.assert_array_equal([it[f"{m}_0"] for it in items], g[f"{tag}_m0"])
+    np.testing.assert_array_equal([it[f"{m}_1"] for it in items], g[f"{tag}_m1"])
+    np.testing.assert_array_equal(np.stack([it["parameters_0"].numpy()[::7] for it in items]), g[f"{tag}_p0"])
+    np.testing.assert_array_equal(np.stack([it["parameters_1"].numpy()[::7] for it in items]), g[f"{tag}_p1"])
+
+
+def test_flat_db_round_trip(tmp_path):
+    """Host logic of the product's storage back-end: write_flat_db -> FlatDb returns every value bit for bit."""
+    from gpt_amd import data as gdata
+    from tests.cases import make_pair_dataset
+    dbs = make_pair_dataset(str(tmp_path / "src"), "cifar")
+    for path, db in dbs.items():
+        dst = str(tmp_path / "flat" / path.split("/")[-1])
+        gdata.write_flat_db(dst, db.items())
+        flat = gdata.FlatDb(dst)
+        assert sorted(flat.keys()) == sorted(db.keys())
+        for k, v in db.items():
+            assert k in flat and torch.equal(flat[k], v)

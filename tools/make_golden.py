@@ -348,8 +348,58 @@ def g12_cnn_eval():
          loss=np.array(losses), err=np.array(errs))
 
 
+# ------------------------------------------------------------------ G13: checkpoint-pair dataset
+def g13_pairs():
+    """The reference's ParameterDataset over synthetic run directories.  py-lmdb is absent, so its Database is replaced
+    by the dict the synthetic generator returns; Gpt.tasks / Gpt.download (task registry, downloader: they import wandb-era
+    packages) are replaced by the two names dataset_lmdb.py uses from them."""
+    import tempfile
+    import data_gen.train_mnist as tm
+    import data_gen.train_cifar10 as tc
+    from tests.cases import PAIR_CASES, make_pair_dataset
+    tasks = types.ModuleType("Gpt.tasks")
+    tasks.TASK_METADATA = {
+        "mnist_loss": {"constructor": lambda: tm.MLP(w_h=10), "aug_fn": tm.random_permute_mlp, "minimize": True},
+        "cifar10_error": {"constructor": tc.ConvNet, "aug_fn": tc.random_permute_cnn, "minimize": True}}
+    dl = types.ModuleType("Gpt.download")
+    dl.find_checkpoints = lambda d: None
+    sys.modules["Gpt.tasks"], sys.modules["Gpt.download"] = tasks, dl
+    import Gpt.data.dataset_lmdb as ref_ds
+    out = {}
+    for case, c in PAIR_CASES.items():
+        with tempfile.TemporaryDirectory() as root:
+            dbs = make_pair_dataset(root, case)
+            ref_ds.Database = lambda path, map_size=None: dbs[path]
+            for split in ("train", "test"):
+                ds = ref_ds.ParameterDataset(dataset_dir=root, dataset_name=c["dataset_name"], split=split,
+                                             num_test_runs=c["num_test_runs"], train_metric=c["train_metric"],
+                                             openai_coeff=c["openai_coeff"], permute_augment=c["augment"], download=False,
+                                             target_epoch_size=1000)
+                torch.manual_seed(c["seed"] + 1)
+                items = [ds[i] for i in c["items"]]
+                tag = f"{case}_{split}"
+                m = c["train_metric"]
+                out[f"{tag}_runs"] = np.array(ds.runs)
+                out[f"{tag}_sizes"] = np.array(ds.parameter_sizes)
+                out[f"{tag}_scalars"] = np.array([ds.min_val, ds.max_val, ds.optimal_test_loss, float(ds.epoch_size),
+                                                  *ds.get_range(normalize=True)])
+                out[f"{tag}_key0"] = np.array([it["checkpoint_key_0"] for it in items])
+                out[f"{tag}_key1"] = np.array([it["checkpoint_key_1"] for it in items])
+                out[f"{tag}_run"] = np.array([it["run_name"] for it in items])
+                out[f"{tag}_spacing"] = np.array([it["step_spacing"] for it in items])
+                out[f"{tag}_m0"] = np.array([it[f"{m}_0"] for it in items])
+                out[f"{tag}_m1"] = np.array([it[f"{m}_1"] for it in items])
+                out[f"{tag}_p0"] = np.stack([it["parameters_0"].numpy()[::7] for it in items])
+                out[f"{tag}_p1"] = np.stack([it["parameters_1"].numpy()[::7] for it in items])
+                out[f"{tag}_net"] = ds.get_run_network(len(ds.runs) - 1, iter=2, normalize=True, augment=False).numpy()[::7]
+    save("g13_pairs", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g13":          # only the pair-dataset fixture (added after G1-G12)
+        g13_pairs()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g12":          # only the ConvNet fixture (added after G1-G11)
         g12_cnn_eval()
         sys.exit(0)
@@ -378,3 +428,4 @@ if __name__ == "__main__":
     g11_ddim("mnist_small", "50", "r50_eta05", 0.5)
     g11_ddim("cifar_small", "ddim25", "ddim25_eta1_eps_clip", 1.0, predict_xstart=False, clip=True)
     g12_cnn_eval()
+    g13_pairs()
