@@ -141,6 +141,8 @@ def main():
     ap.add_argument("--mode", default="sample", choices=["sample", "train"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--case", default="mnist", choices=["mnist", "cifar", "cifar_big"])
+    ap.add_argument("--data", default="synthetic", choices=["synthetic", "store"],
+                    help="--mode train: 'store' draws every batch from an HBM-resident checkpoint store (g.pt_amd/data.py)")
     ap.add_argument("--augment", action="store_true",
                     help="train mode: on-device permutation augmentation of every checkpoint pair (configs[4])")
     ap.add_argument("--batch", type=int, default=None, help="rows per GPU (default 320 sample / 128 train)")

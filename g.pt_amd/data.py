@@ -61,6 +61,27 @@ def write_flat_db(path, items):
         json.dump({"keys": index}, f)
 
 
+def write_synthetic_dataset(root, dataset_name="mnist_loss", runs=64, ckpts=64, train_metric="avg_test_loss", seed=0, std=0.25):
+    """A checkpoint dataset of the reference's directory layout (one directory per run: runs.json + the flat value file)
+    filled with seeded noise: for benchmarks and smoke runs where the real 68-275 GB sets are not present."""
+    sizes = {"mlp": [7840, 10, 100, 10], "cnn": [432, 4608, 320, 10]}[_ARCH[dataset_name]["kind"]]
+    D, g = sum(sizes), torch.Generator().manual_seed(seed)
+    opt_key = f"optimal_{train_metric}".replace("_avg", "")
+    for r in range(runs):
+        run, ck, items = f"r{r:05d}", {}, []
+        vals = torch.randn(ckpts, D, generator=g) * std
+        for i in range(ckpts):
+            key = f"{run}/ep{i:03d}_it00000.pt"
+            items.append((key, vals[i]))
+            ck[key] = {train_metric: 2.3 - 2.0 * i / ckpts}
+        items.append((items[0][0] + "_arch", torch.tensor(sizes, dtype=torch.float32)))
+        write_flat_db(os.path.join(root, run), items)
+        series = [v[train_metric] for v in ck.values()]
+        with open(os.path.join(root, run, "runs.json"), "w") as f:
+            json.dump({"checkpoints": ck, "metadata": {train_metric: series, opt_key: min(series),
+                                                       "min_parameter_val": float(vals.min()), "max_parameter_val": float(vals.max())}}, f)
+
+
 def default_open_db(path):
     if os.path.exists(os.path.join(path, FLAT_INDEX)):
         return FlatDb(path)

@@ -220,6 +220,11 @@ def synthetic_pairs(case, B, device, seed):
     return [v.to(device) for v in (w_t, w_t1, loss_t, loss_t1)]
 
 
+def c_std(case):
+    from tests.cases import CASES
+    return CASES[case]["w_std"]
+
+
 def bench_train(args, device, world, rank):
     """bench.py --mode train: configs/train/mnist_loss.yaml hyper-parameters on synthetic checkpoint pairs."""
     import gpt_amd
@@ -246,11 +251,30 @@ def bench_train(args, device, world, rank):
         from . import permute
         arch = permute.MLP_ARCH if case.startswith("mnist") else permute.CNN_ARCH
 
+    store = None
+    if getattr(args, "data", "synthetic") == "store":
+        # the whole input pipeline in the timed step: pairs drawn from a checkpoint store resident in HBM (g.pt_amd/data.py)
+        import tempfile
+        import numpy
+        from . import data as gdata
+        name, metric = ("mnist_loss", "avg_test_loss") if mnist else ("cifar10_error", "avg_test_err")
+        with tempfile.TemporaryDirectory() as root:
+            gdata.write_synthetic_dataset(root, name, runs=64, ckpts=64, train_metric=metric, seed=rank, std=c_std(case))
+            store = gdata.CheckpointStore(root, name, split="train", num_test_runs=0, train_metric=metric, device=device,
+                                          normalizer_name="none", permute_augment=augment, target_epoch_size=1 << 20)
+        order = torch.randperm(len(store), generator=torch.Generator().manual_seed(rank))
+        rng = numpy.random.default_rng([1, rank])
+
     def run(n, first):
         last = None
         for i in range(first, first + n):
             ts.set_lr(lr_at(4e-4, 25000, 5, 0.0, i / iters_per_epoch))
             t, wts = sampler.sample(B, device)
+            if store is not None:
+                b = store.get_batch(order[(i * B) % (len(store) - B):][:B].tolist(), rng)
+                last = ts.step(b["parameters_0"], b["parameters_1"], b[metric + "_0"].to(device, non_blocking=True),
+                               b[metric + "_1"].to(device, non_blocking=True), t, weights=wts)
+                continue
             w_t, w_t1, l_t, l_t1 = batches[i % len(batches)]
             if augment:     # one function-preserving permutation per pair, on the GPU (Gpt/data/augment.py:25-75)
                 seeds = range((i * world + rank) * B, (i * world + rank + 1) * B)
@@ -276,7 +300,10 @@ def bench_train(args, device, world, rank):
         "metric": "train iters/sec (DDP)", "value": 1e3 / ms, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"{cfg_name} step on synthetic checkpoint pairs: q_sample + denoiser "
+        "config": {"workload": f"{cfg_name} step on synthetic checkpoint pairs"
+                               + (" fetched per step from an HBM-resident checkpoint store (pair sampling + gather"
+                                  " + normalisation inside the timed step)" if store is not None else "")
+                               + ": q_sample + denoiser "
                                f"forward/backward + grad all-reduce + clip {clip} + AdamW(4e-4, wd 0.1) + EMA 0.9999; "
                                f"B={B} pairs per GPU (global {B * world})"
                                + ("; on-device permutation augmentation of every pair" if augment else ""),

@@ -2,7 +2,6 @@
 """Batch-fetch rate of the HBM-resident checkpoint store on a synthetic MNIST-shaped dataset.
 Usage: python tools/pairs_bench.py [--runs 200] [--ckpts 200] [--batch 1024]"""
 import argparse
-import json
 import os
 import sys
 import tempfile
@@ -23,20 +22,7 @@ def main():
     a = ap.parse_args()
     D = 7960
     with tempfile.TemporaryDirectory() as root:
-        g = torch.Generator().manual_seed(0)
-        for r in range(a.runs):
-            run, ck, items = f"r{r:05d}", {}, []
-            vals = torch.randn(a.ckpts, D, generator=g) * 0.25
-            for i in range(a.ckpts):
-                key = f"{run}/ep{i:03d}_it00000.pt"
-                items.append((key, vals[i]))
-                ck[key] = {"avg_test_loss": 2.3 - 2.0 * i / a.ckpts}
-            items.append((items[0][0] + "_arch", torch.tensor([7840., 10., 100., 10.])))
-            gdata.write_flat_db(os.path.join(root, run), items)
-            with open(os.path.join(root, run, "runs.json"), "w") as f:
-                json.dump({"checkpoints": ck, "metadata": {"avg_test_loss": [v["avg_test_loss"] for v in ck.values()],
-                                                           "optimal_test_loss": 0.3, "min_parameter_val": -1.0,
-                                                           "max_parameter_val": 1.0}}, f)
+        gdata.write_synthetic_dataset(root, "mnist_loss", a.runs, a.ckpts)
         t0 = time.time()
         ds = gdata.CheckpointStore(root, "mnist_loss", split="train", num_test_runs=0, permute_augment=True)
         torch.cuda.synchronize()
