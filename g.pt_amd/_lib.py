@@ -94,6 +94,8 @@ _PROTOS = {
     "gpt_denoiser_backward": ([C.POINTER(Model), C.POINTER(Workspace), C.POINTER(Backward), vp, vp, vp, i32, vp], i32),
     "gpt_denoiser_backward_stages": ([C.POINTER(Model), C.POINTER(Workspace), C.POINTER(Backward), vp, vp, vp, i32, i32, i32,
                                       vp], i32),
+    "gpt_ddim_reverse_step": ([vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, i32, i32, vp], i32),
+    "gpt_prior_bpd": ([vp, f32, f32, vp, i32, i32, vp], i32),
     "gpt_pair_gather": ([vp, i64, i64, vp, vp, vp, C.c_float, vp, vp, i32, i32, vp], i32),
     "gpt_cnn_eval": ([vp, vp, vp, i64, vp, i32, vp, vp, i32, i32, vp], i32),
     "gpt_mlp_head": ([vp, i64, vp, i64, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp], i32),

@@ -111,14 +111,18 @@ __global__ __launch_bounds__(256) void ddim_kernel(const float* __restrict__ mo,
                                                    const float* __restrict__ noise, const int64_t* __restrict__ t,
                                                    const float* __restrict__ coef, const float* __restrict__ acp,
                                                    int predict_xstart, int use_clamp, float lo, float hi, float eta,
-                                                   float* __restrict__ xout, float* __restrict__ x0out, int B, int DV) {
+                                                   float* __restrict__ xout, float* __restrict__ x0out, int B, int DV,
+                                                   int reverse_steps) {
   const int b = blockIdx.y;
   const int64_t tb = t[b];
   DdimScal p;
   p.recip = coef[tb * NC + GPT_C_RECIP];
   p.recipm1 = coef[tb * NC + GPT_C_RECIPM1];
-  const float ab = acp[tb], abp = tb > 0 ? acp[tb - 1] : 1.0f;
-  p.sigma = (eta * sqrtf((1.0f - abp) / (1.0f - ab))) * sqrtf(1.0f - ab / abp);
+  // reverse_steps > 0: the deterministic reverse ODE (ddim_reverse_sample, gaussian_diffusion.py:559-592) = the same
+  // update towards alphas_cumprod_next (0 after the last step) with sigma = 0
+  const float ab = acp[tb];
+  const float abp = reverse_steps > 0 ? (tb + 1 < reverse_steps ? acp[tb + 1] : 0.0f) : (tb > 0 ? acp[tb - 1] : 1.0f);
+  p.sigma = reverse_steps > 0 ? 0.0f : (eta * sqrtf((1.0f - abp) / (1.0f - ab))) * sqrtf(1.0f - ab / abp);
   p.sq_abp = sqrtf(abp);
   p.dir = sqrtf((1.0f - abp) - p.sigma * p.sigma);
   p.mask = tb != 0 ? 1.0f : 0.0f;
@@ -162,6 +166,25 @@ __global__ __launch_bounds__(256) void mse_rows_kernel(const float* __restrict__
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) mse[b] = ((part[0] + part[1]) + (part[2] + part[3])) / (float)D;
+}
+
+// _prior_bpd (gaussian_diffusion.py:783-797): KL(q(x_T | x_0) || N(0, I)) per row in bits per dimension, with normal_kl's
+// term order (diffusion_utils.py:35-41: 0.5 * (-1 + logvar2 - logvar1 + exp(logvar1 - logvar2) + (mean1 - mean2)^2 *
+// exp(-logvar2)), mean2 = logvar2 = 0).  One 256-thread block per row.
+__global__ __launch_bounds__(256) void prior_bpd_kernel(const float* __restrict__ x, float s, float lv1, float* __restrict__ out,
+                                                        int D) {
+  __shared__ float part[4];
+  const float* row = x + (int64_t)blockIdx.x * D;
+  const float base = ((-1.0f + 0.0f) - lv1) + expf(lv1 - 0.0f);
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < D; i += 256) {
+    const float m = s * row[i];
+    acc += 0.5f * (base + (m * m) * 1.0f);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = (((part[0] + part[1]) + (part[2] + part[3])) / (float)D) / 0.6931471805599453f;
 }
 
 __global__ __launch_bounds__(256) void mse_rows_bwd_kernel(const float* __restrict__ target, const float* __restrict__ out,
@@ -300,12 +323,40 @@ extern "C" int gpt_ddim_step(const float* model_out, const float* x_t, const flo
   hipStream_t s = (hipStream_t)stream;
 #define DDIM(VV)                                                                                                       \
   hipLaunchKernelGGL(ddim_kernel<VV>, grid, dim3(256), 0, s, model_out, x_t, noise, t, coef, alphas_cumprod,             \
-                     predict_xstart, use_clamp, lo, hi, eta, x_out, pred_xstart, B, D / VV)
+                     predict_xstart, use_clamp, lo, hi, eta, x_out, pred_xstart, B, D / VV, 0)
   if (V == 4) DDIM(4);
   else if (V == 2) DDIM(2);
   else DDIM(1);
 #undef DDIM
   return gpt_launch_status("gpt_ddim_step");
+}
+
+extern "C" int gpt_ddim_reverse_step(const float* model_out, const float* x_t, const int64_t* t, const float* coef,
+                                     const float* alphas_cumprod, int n_steps, int predict_xstart, int use_clamp, float lo,
+                                     float hi, float* x_out, float* pred_xstart, int B, int D, void* stream) {
+  GPT_REQUIRE(model_out && x_t && t && coef && alphas_cumprod && x_out && B > 0 && D > 0 && n_steps > 0,
+              "gpt_ddim_reverse_step: bad arguments");
+  GPT_REQUIRE(B <= 65535, "gpt_ddim_reverse_step: B > 65535");
+  const int V = vec_width(D, model_out, x_t, nullptr, x_out, pred_xstart);
+  const int gx = blocks_for(D / V) > 8 ? 8 : blocks_for(D / V);
+  const dim3 grid(gx, B);
+  hipStream_t s = (hipStream_t)stream;
+#define DDIMR(VV)                                                                                                      \
+  hipLaunchKernelGGL(ddim_kernel<VV>, grid, dim3(256), 0, s, model_out, x_t, (const float*)nullptr, t, coef,          \
+                     alphas_cumprod, predict_xstart, use_clamp, lo, hi, 0.0f, x_out, pred_xstart, B, D / VV, n_steps)
+  if (V == 4) DDIMR(4);
+  else if (V == 2) DDIMR(2);
+  else DDIMR(1);
+#undef DDIMR
+  return gpt_launch_status("gpt_ddim_reverse_step");
+}
+
+extern "C" int gpt_prior_bpd(const float* x_start, float sqrt_ac_last, float log_one_minus_ac_last, float* out, int B, int D,
+                             void* stream) {
+  GPT_REQUIRE(x_start && out && B > 0 && D > 0, "gpt_prior_bpd: bad arguments");
+  hipLaunchKernelGGL(prior_bpd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x_start, sqrt_ac_last, log_one_minus_ac_last,
+                     out, D);
+  return gpt_launch_status("gpt_prior_bpd");
 }
 
 extern "C" int gpt_mse_rows(const float* target, const float* out, float* mse, int B, int D, void* stream) {

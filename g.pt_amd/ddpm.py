@@ -196,6 +196,41 @@ class GaussianDiffusion:
                 "gpt_q_sample")
         return out.view(x_start.shape)
 
+    def q_mean_variance(self, x_start, t):
+        """q(x_t | x_0): (mean, variance, log_variance), all of x_start's shape (gaussian_diffusion.py:196-207); the two
+        variances are broadcast views of the per-sample scalars."""
+        B = x_start.shape[0]
+        t = t.long().contiguous()
+        x0 = x_start.detach().float().contiguous()
+        mean = self.q_sample(x0, t, noise=torch.zeros_like(x0))           # sqrt(ac) * x0 + sqrt(1 - ac) * 0
+        shape = [B] + [1] * (x_start.dim() - 1)
+        var = torch.from_numpy(1.0 - self.alphas_cumprod).to(x0.device)[t].float()
+        logvar = torch.from_numpy(self.log_one_minus_alphas_cumprod).to(x0.device)[t].float()
+        return mean, var.view(shape).expand_as(x0), logvar.view(shape).expand_as(x0)
+
+    def q_posterior_mean_variance(self, x_start, x_t, t):
+        """q(x_{t-1} | x_t, x_0) (gaussian_diffusion.py:226-246): the mean through the fused posterior kernel."""
+        assert x_start.shape == x_t.shape
+        B = x_t.shape[0]
+        t = t.long().contiguous()
+        x0, xt = x_start.detach().float().contiguous(), x_t.detach().float().contiguous()
+        mean, _ = self._posterior(x0, xt, None, t, None, is_xstart=True)
+        shape = [B] + [1] * (x_t.dim() - 1)
+        var = torch.from_numpy(self.posterior_variance).to(xt.device)[t].float()
+        logvar = torch.from_numpy(self.posterior_log_variance_clipped).to(xt.device)[t].float()
+        return mean, var.view(shape).expand_as(xt), logvar.view(shape).expand_as(xt)
+
+    def _prior_bpd(self, x_start):
+        """Prior KL term of the variational bound in bits per dimension, one value per row (gaussian_diffusion.py:783-797;
+        Gpt/data/prepare_checkpoints.py:98 prints its mean for the chosen openai_coeff)."""
+        B = x_start.shape[0]
+        x0 = x_start.detach().float().contiguous().view(B, -1)
+        out = torch.empty(B, dtype=torch.float32, device=x0.device)
+        s = float(np.float32(self.sqrt_alphas_cumprod[-1]))
+        lv = float(np.float32(self.log_one_minus_alphas_cumprod[-1]))
+        L.check(L.lib().gpt_prior_bpd(L.ptr(x0), s, lv, L.ptr(out), B, x0.shape[1], L.stream()), "gpt_prior_bpd")
+        return out
+
     # ---- reverse process
     def _posterior(self, model_output, x, noise, t, clamp, want_xstart=False, is_xstart=None):
         if is_xstart is None:
@@ -413,6 +448,31 @@ class GaussianDiffusion:
             float(eta), L.ptr(out), L.ptr(x0), B, D, L.stream()), "gpt_ddim_step")
         return {"sample": out, "pred_xstart": x0}
 
+    def ddim_reverse_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
+                            eta=0.0):
+        """x_{t+1} from x_t by the DDIM reverse ODE (gaussian_diffusion.py:559-592)."""
+        assert eta == 0.0, "Reverse ODE only for deterministic path"
+        if cond_fn is not None:
+            raise NotImplementedError("cond_fn guidance is never used by G.pt and is not on the HIP path")
+        self._check_types()
+        model_kwargs = model_kwargs or {}
+        assert t.shape == (x.shape[0],)
+        x = x.detach().float().contiguous()
+        t = t.long().contiguous()
+        model_output = model(x, t, **model_kwargs)
+        if isinstance(model_output, tuple):
+            model_output = model_output[0]
+        model_output = model_output.detach().float().contiguous()
+        model_output, clamp, is_x0 = self._apply_denoised_fn(model_output, x, t, clip_denoised, denoised_fn)
+        B, D = x.shape[0], x[0].numel()
+        out, x0 = torch.empty_like(x), torch.empty_like(x)
+        lo, hi = clamp if clamp is not None else (0.0, 0.0)
+        L.check(L.lib().gpt_ddim_reverse_step(
+            L.ptr(model_output), L.ptr(x), L.ptr(t), L.ptr(self.coef_table(x.device)), L.ptr(self._ac_table(x.device)),
+            self.num_timesteps, int(is_x0), int(clamp is not None), lo, hi, L.ptr(out), L.ptr(x0), B, D, L.stream()),
+            "gpt_ddim_reverse_step")
+        return {"sample": out, "pred_xstart": x0}
+
     def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                          model_kwargs=None, device=None, progress=False, eta=0.0, step_noise=None, seed=None):
         """gaussian_diffusion.py:594-628.  Fused into one host call (gpt_ddim_sample_loop) under the same conditions as
@@ -501,6 +561,9 @@ class SpacedDiffusion(GaussianDiffusion):
 
     def p_sample(self, model, *args, **kwargs):
         return super().p_sample(self._wrap_model(model), *args, **kwargs)
+
+    def ddim_reverse_sample(self, model, *args, **kwargs):
+        return super().ddim_reverse_sample(self._wrap_model(model), *args, **kwargs)
 
     def ddim_sample(self, model, *args, **kwargs):
         return super().ddim_sample(self._wrap_model(model), *args, **kwargs)

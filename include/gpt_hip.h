@@ -147,6 +147,17 @@ int gpt_ddim_step(const float* model_out, const float* x_t, const float* noise, 
                   const float* alphas_cumprod, int predict_xstart, int use_clamp, float lo, float hi, float eta,
                   float* x_out, float* pred_xstart, int B, int D, void* stream);
 
+/* Deterministic reverse ODE step x_t -> x_{t+1} (ddim_reverse_sample, gaussian_diffusion.py:559-592): the gpt_ddim_step
+ * update towards alphas_cumprod_next[t] (= alphas_cumprod[t + 1], 0 for t = n_steps - 1) with eta = 0 and no noise. */
+int gpt_ddim_reverse_step(const float* model_out, const float* x_t, const int64_t* t, const float* coef,
+                          const float* alphas_cumprod, int n_steps, int predict_xstart, int use_clamp, float lo, float hi,
+                          float* x_out, float* pred_xstart, int B, int D, void* stream);
+
+/* out[b] = mean_i KL(N(s * x[b,i], exp(lv)) || N(0, 1)) / ln 2  with s = sqrt_alphas_cumprod[T-1], lv =
+ * log_one_minus_alphas_cumprod[T-1] (_prior_bpd, gaussian_diffusion.py:783-797, normal_kl of diffusion_utils.py:15-41;
+ * Gpt/data/prepare_checkpoints.py:98 reports it when choosing openai_coeff). */
+int gpt_prior_bpd(const float* x_start, float sqrt_ac_last, float log_one_minus_ac_last, float* out, int B, int D, void* stream);
+
 /* mse[b] = mean_d (target - out)^2   (diffusion_utils.py:8-12 over gaussian_diffusion.py:773) */
 int gpt_mse_rows(const float* target, const float* out, float* mse, int B, int D, void* stream);
 /* grad_out[b, :] = scale[b] * 2 (out - target) / D     (backward of the above; scale = dL/dmse) */

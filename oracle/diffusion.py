@@ -61,6 +61,8 @@ class Tables:
         al = 1.0 - b
         self.alphas_cumprod = np.cumprod(al, axis=0)
         self.alphas_cumprod_prev = np.append(1.0, self.alphas_cumprod[:-1])
+        self.alphas_cumprod_next = np.append(self.alphas_cumprod[1:], 0.0)
+        self.log_one_minus_alphas_cumprod = np.log(1.0 - self.alphas_cumprod)
         self.sqrt_alphas_cumprod = np.sqrt(self.alphas_cumprod)
         self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - self.alphas_cumprod)
         self.sqrt_recip_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod)
@@ -136,6 +138,37 @@ def ddim_step(tb, model_out, x_t, t, noise, eta=0.0, predict_xstart=True, clip=F
     mean = x0 * _sqrt32(abp) + _sqrt32(1 - abp - sigma ** 2) * eps
     mask = (t != 0).float()[:, None]
     return mean + mask * sigma * noise, x0
+
+
+def ddim_reverse_step(tb, model_out, x_t, t, predict_xstart=True, clip=False):
+    """ddim_reverse_sample (gaussian_diffusion.py:559-592), fp32 op by op."""
+    x0 = model_out if predict_xstart else xstart_from_eps(tb, x_t, t, model_out)
+    if clip:
+        x0 = x0.clamp(-1, 1)
+    eps = (_take(tb.sqrt_recip_alphas_cumprod, t) * x_t - x0) / _take(tb.sqrt_recipm1_alphas_cumprod, t)
+    abn = _take(tb.alphas_cumprod_next, t)
+    return x0 * _sqrt32(abn) + _sqrt32(1 - abn) * eps, x0
+
+
+def q_mean_variance(tb, x0, t):
+    """gaussian_diffusion.py:196-207 (per-sample scalars for the two variances)."""
+    return (_take(tb.sqrt_alphas_cumprod, t) * x0, _take(1.0 - tb.alphas_cumprod, t)[:, 0],
+            _take(tb.log_one_minus_alphas_cumprod, t)[:, 0])
+
+
+def q_posterior_mean_variance(tb, x0, x_t, t):
+    """gaussian_diffusion.py:226-246."""
+    mean = _take(tb.posterior_mean_coef1, t) * x0 + _take(tb.posterior_mean_coef2, t) * x_t
+    return mean, _take(tb.posterior_variance, t)[:, 0], _take(tb.posterior_log_variance_clipped, t)[:, 0]
+
+
+def prior_bpd(tb, x0):
+    """_prior_bpd (gaussian_diffusion.py:783-797) with normal_kl (diffusion_utils.py:15-41) against N(0, I)."""
+    t = torch.full((x0.shape[0],), tb.T - 1, dtype=torch.long)
+    mean1, lv1 = _take(tb.sqrt_alphas_cumprod, t) * x0, _take(tb.log_one_minus_alphas_cumprod, t).expand_as(x0)
+    lv2 = torch.tensor(0.0)
+    kl = 0.5 * (-1.0 + lv2 - lv1 + torch.exp(lv1 - lv2) + ((mean1 - 0.0) ** 2) * torch.exp(-lv2))
+    return kl.mean(dim=1) / np.log(2.0)
 
 
 def ddim_sample_loop(tb, model_fn, start, step_noise, eta=0.0, predict_xstart=True, clip=False):

@@ -479,6 +479,31 @@ def test_batched_mlp_eval_golden_and_oracle(golden):
         gpt_amd.mlp_test_losses(nets, imgs, labels)                 # CPU tensors: no fallback
 
 
+@pytest.mark.parametrize("tag,respacing,px", [("full_x0", "", True), ("r50_eps", "50", False)])
+def test_diffusion_misc_golden(golden, tag, respacing, px):
+    """ddim_reverse_sample (gpt_ddim_reverse_step), q_posterior_mean_variance (fused posterior kernel), q_mean_variance
+    (gpt_q_sample) BIT-EXACT against the reference's fixture; _prior_bpd (gpt_prior_bpd) to 1e-6 (row-mean order)."""
+    g = golden("g14_diffusion_misc")
+    d = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=px, noise_schedule="linear", steps=1000,
+                                 timestep_respacing=respacing)
+    x, x0, mo, t = (torch.from_numpy(g[k]).to(DEV) for k in ("x", "x0", "mo", f"{tag}_t"))
+    r = d.ddim_reverse_sample(lambda xx, tt, **kw: mo, x, t, clip_denoised=(tag == "r50_eps"))
+    np.testing.assert_array_equal(r["sample"].cpu().numpy(), g[f"{tag}_rev"])
+    np.testing.assert_array_equal(r["pred_xstart"].cpu().numpy(), g[f"{tag}_rev_x0"])
+    m, v, lv = d.q_mean_variance(x0, t)
+    assert v.shape == x0.shape and lv.shape == x0.shape
+    np.testing.assert_array_equal(m.cpu().numpy(), g[f"{tag}_qm"])
+    np.testing.assert_array_equal(v[:, 0].cpu().numpy(), g[f"{tag}_qv"])
+    np.testing.assert_array_equal(lv[:, 0].cpu().numpy(), g[f"{tag}_qlv"])
+    m, v, lv = d.q_posterior_mean_variance(x0, x, t)
+    np.testing.assert_array_equal(m.cpu().numpy(), g[f"{tag}_pm"])
+    np.testing.assert_array_equal(v[:, 0].cpu().numpy(), g[f"{tag}_pv"])
+    np.testing.assert_array_equal(lv[:, 0].cpu().numpy(), g[f"{tag}_plv"])
+    np.testing.assert_allclose(d._prior_bpd(x0).cpu().numpy(), g[f"{tag}_bpd"], rtol=1e-6)
+    with pytest.raises(AssertionError):
+        d.ddim_reverse_sample(lambda xx, tt, **kw: mo, x, t, eta=0.5)
+
+
 def test_batched_cnn_eval_golden_and_oracle(golden):
     """All sampled CIFAR-10 ConvNets scored by one fused kernel (conv1 VALU, conv2 fp32 MFMA, pool, fc, loss): fp32
     throughout, summation order differs from ATen's convolutions -> rtol 2e-5 on the mean loss; the error count is exact

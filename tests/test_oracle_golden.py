@@ -201,3 +201,19 @@ def test_flat_db_round_trip(tmp_path):
         assert sorted(flat.keys()) == sorted(db.keys())
         for k, v in db.items():
             assert k in flat and torch.equal(flat[k], v)
+
+
+@pytest.mark.parametrize("tag,respacing,px", [("full_x0", "", True), ("r50_eps", "50", False)])
+def test_g14_diffusion_misc(golden, tag, respacing, px):
+    """ddim_reverse_sample / q_mean_variance / q_posterior_mean_variance bit for bit, _prior_bpd to the row mean's rounding."""
+    g = golden("g14_diffusion_misc")
+    tb = odf.Tables(1000, respacing)
+    x, x0, mo, t = (torch.from_numpy(g[k]) for k in ("x", "x0", "mo", f"{tag}_t"))
+    rev, rx0 = odf.ddim_reverse_step(tb, mo, x, t, predict_xstart=px, clip=(tag == "r50_eps"))
+    np.testing.assert_array_equal(rev.numpy(), g[f"{tag}_rev"])
+    np.testing.assert_array_equal(rx0.numpy(), g[f"{tag}_rev_x0"])
+    for got, want in zip(odf.q_mean_variance(tb, x0, t), ("qm", "qv", "qlv")):
+        np.testing.assert_array_equal(got.numpy(), g[f"{tag}_{want}"])
+    for got, want in zip(odf.q_posterior_mean_variance(tb, x0, x, t), ("pm", "pv", "plv")):
+        np.testing.assert_array_equal(got.numpy(), g[f"{tag}_{want}"])
+    np.testing.assert_allclose(odf.prior_bpd(tb, x0).numpy(), g[f"{tag}_bpd"], rtol=1e-6)

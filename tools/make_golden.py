@@ -395,8 +395,34 @@ def g13_pairs():
     save("g13_pairs", **out)
 
 
+# ------------------------------------------------------------------ G14: remaining GaussianDiffusion surface
+def g14_diffusion_misc():
+    """ddim_reverse_sample, q_mean_variance, q_posterior_mean_variance and _prior_bpd of the reference on seeded inputs
+    (the "model" is a closure returning a fixed tensor: these functions only post-process its output)."""
+    out = {}
+    g = torch.Generator().manual_seed(77)
+    B, D = 4, 301
+    x, x0, mo = torch.randn(B, D, generator=g), torch.randn(B, D, generator=g) * 0.5, torch.randn(B, D, generator=g) * 0.7
+    out["x"], out["x0"], out["mo"] = x.numpy(), x0.numpy(), mo.numpy()
+    for tag, respacing, px, ts in (("full_x0", "", True, [0, 17, 500, 999]), ("r50_eps", "50", False, [0, 3, 25, 49])):
+        d = create_diffusion(learn_sigma=False, predict_xstart=px, noise_schedule="linear", steps=1000,
+                             timestep_respacing=respacing)
+        t = torch.tensor(ts)
+        r = d.ddim_reverse_sample(lambda xx, tt, **kw: mo, x, t, clip_denoised=(tag == "r50_eps"))
+        out[f"{tag}_t"], out[f"{tag}_rev"], out[f"{tag}_rev_x0"] = t.numpy(), r["sample"].numpy(), r["pred_xstart"].numpy()
+        m, v, lv = d.q_mean_variance(x0, t)
+        out[f"{tag}_qm"], out[f"{tag}_qv"], out[f"{tag}_qlv"] = m.numpy(), v[:, 0].numpy(), lv[:, 0].numpy()
+        m, v, lv = d.q_posterior_mean_variance(x0, x, t)
+        out[f"{tag}_pm"], out[f"{tag}_pv"], out[f"{tag}_plv"] = m.numpy(), v[:, 0].numpy(), lv[:, 0].numpy()
+        out[f"{tag}_bpd"] = d._prior_bpd(x0).numpy()
+    save("g14_diffusion_misc", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g14":
+        g14_diffusion_misc()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g13":          # only the pair-dataset fixture (added after G1-G12)
         g13_pairs()
         sys.exit(0)
@@ -429,3 +455,4 @@ if __name__ == "__main__":
     g11_ddim("cifar_small", "ddim25", "ddim25_eta1_eps_clip", 1.0, predict_xstart=False, clip=True)
     g12_cnn_eval()
     g13_pairs()
+    g14_diffusion_misc()
