@@ -14,6 +14,7 @@
 //                        from ds_read_b64_tr_b16, 12 LDS reads instead of 48 two-byte global loads per lane.
 // fp32: v_mfma_f32_32x32x2_f32 (exact).  bf16: v_mfma_f32_32x32x16_bf16, P rounded to bf16 once.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -26,9 +27,11 @@ constexpr int v_pitch = HD == 128 ? 320 : 192;
 
 __device__ __forceinline__ int key_of(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
-template <typename T, int HD>
-__global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ y, int B, int Ttok,
-                                                        int n_head) {
+// OUT_LDS (bf16): the output tile goes back through the wave's LDS tile (the V tile has been consumed by then) so that it
+// leaves as 16-byte stores that cover whole rows of the head (HD * 2 contiguous bytes) instead of one 8-byte store per lane
+// and (row, 4 head-dims): 12 -> 5 store instructions per wave at HD = 96, every one made of full lines.
+template <typename T, int HD, bool OUT_LDS>
+__device__ __forceinline__ void attention_body(const T* __restrict__ qkv, T* __restrict__ y, int B, int Ttok, int n_head) {
   const int lane = threadIdx.x & 63;
   const int r = lane & 31, hh = lane >> 5;
   const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -44,8 +47,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
 
   // bf16: V tile -> registers now (in flight during the score MFMAs), -> LDS after them
   constexpr int VP = v_pitch<HD>, CPR = HD / 8, NVL = (32 * CPR + 63) / 64;
-  __shared__ __attribute__((aligned(16))) char vsm[sizeof(T) == 2 ? 4 * 32 * VP : 16];
-  char* vt = vsm + (sizeof(T) == 2 ? (threadIdx.x >> 6) * 32 * VP : 0);
+  constexpr int OP = HD * 2 + 16;                                      // pitch of the output tile (OUT_LDS), see the end
+  constexpr int TILE = 32 * (OUT_LDS && OP > VP ? OP : VP);            // per wave: the V tile, later the output tile
+  __shared__ __attribute__((aligned(16))) char vsm[sizeof(T) == 2 ? 4 * TILE : 16];
+  char* vt = vsm + (sizeof(T) == 2 ? (threadIdx.x >> 6) * TILE : 0);
   u32x4 vreg[NVL];
   if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -152,6 +157,32 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     }
   }
 
+  if constexpr (OUT_LDS && sizeof(T) == 2) {
+    // pitch HD * 2 + 16 bytes: the 16 rows of a ds_write_b64 lane group start (HD / 2 + 4) r banks apart = 16 distinct
+    // multiples of 4 banks for HD = 32, 64, 96, 128; Ttok * pitch <= 32 * v_pitch<HD>
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the transposing reads of V have returned (their MFMAs consumed them)
+    if (rvalid) {
+#pragma unroll
+      for (int t = 0; t < ND; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 o;
+          o.x = pack_bf16x2(O[t][4 * g + 0], O[t][4 * g + 1]);
+          o.y = pack_bf16x2(O[t][4 * g + 2], O[t][4 * g + 3]);
+          *reinterpret_cast<uint2*>(vt + r * OP + (t * 32 + 8 * g + 4 * hh) * 2) = o;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    T* yb = y + (int64_t)b * Ttok * d + h * HD;
+    const int nchunk = Ttok * CPR;
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+      const int c = lane + 64 * i, row = c / CPR, col = c - row * CPR;
+      if (c < nchunk) *reinterpret_cast<u32x4*>(yb + (int64_t)row * d + col * 8) = *reinterpret_cast<const u32x4*>(vt + row * OP + col * 16);
+    }
+    return;
+  }
   // O^T[dd][query r]: registers 4g..4g+3 are 4 consecutive head-dims -> one 8/16-byte store per group
   if (rvalid) {
     T* yr = y + ((int64_t)b * Ttok + r) * d + h * HD;
@@ -173,10 +204,33 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
   }
 }
 
+template <typename T, int HD, bool OUT_LDS>
+__global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ y, int B, int Ttok, int n_head) {
+  attention_body<T, HD, OUT_LDS>(qkv, y, B, Ttok, n_head);
+}
+// at most 96 registers: 5 waves per SIMD = 20 per CU (B = 320, 16 heads: 5120 waves = exactly one round of 256 CUs)
+template <typename T, int HD, bool OUT_LDS>
+__global__ __launch_bounds__(256, 5) void attention_kernel_w5(const T* __restrict__ qkv, T* __restrict__ y, int B, int Ttok, int n_head) {
+  attention_body<T, HD, OUT_LDS>(qkv, y, B, Ttok, n_head);
+}
+
 template <typename T>
 int launch(const void* qkv, void* y, int B, int T_, int n_head, int hd, hipStream_t s) {
   const dim3 grid((B * n_head + 3) / 4), block(256);
-#define ATT(HD) hipLaunchKernelGGL((attention_kernel<T, HD>), grid, block, 0, s, (const T*)qkv, (T*)y, B, T_, n_head)
+  // variant (A/B measurements, GPT_ATT_VARIANT): bit 0 = output through LDS, bit 1 = 5 waves per SIMD.  Same box, B = 320,
+  // HD = 96: 28.6 us (0) -> 23.2 (1) -> 24.3 (2) -> 21.0 (3).  HD = 128 keeps 4 waves per SIMD (its 40 KiB of LDS per workgroup
+  // allow no more).
+  static const int variant = [] { const char* e = getenv("GPT_ATT_VARIANT"); return e ? atoi(e) : 3; }();
+#define ATT_ARGS grid, block, 0, s, (const T*)qkv, (T*)y, B, T_, n_head
+#define ATT(HD)                                                                                       \
+  do {                                                                                                \
+    if constexpr (HD <= 96) {                                                                         \
+      if (variant == 2) { hipLaunchKernelGGL((attention_kernel_w5<T, HD, false>), ATT_ARGS); break; } \
+      if (variant == 3) { hipLaunchKernelGGL((attention_kernel_w5<T, HD, true>), ATT_ARGS); break; }  \
+    }                                                                                                 \
+    if (variant == 0) hipLaunchKernelGGL((attention_kernel<T, HD, false>), ATT_ARGS);                 \
+    else hipLaunchKernelGGL((attention_kernel<T, HD, true>), ATT_ARGS);                               \
+  } while (0)
   switch (hd) {
     case 32: ATT(32); break;
     case 64: ATT(64); break;
@@ -185,6 +239,7 @@ int launch(const void* qkv, void* y, int B, int T_, int n_head, int hd, hipStrea
     default: gpt_set_error("gpt_attention: unsupported head dim %d", hd); return -1;
   }
 #undef ATT
+#undef ATT_ARGS
   return gpt_launch_status("gpt_attention");
 }
 

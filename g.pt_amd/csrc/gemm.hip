@@ -82,7 +82,8 @@ __global__ __launch_bounds__(WM * 128, WM) void gemm_nt_kernel(GemmArgs<T> g) {
 
   // XCD-aware, bijective remap: blocks b, b+8, ... share an XCD (and its L2); give each XCD a
   // contiguous run of tiles so neighbours re-use the same A panel / W panels from that L2.
-  const int nwg = gridDim.x, bid = blockIdx.x;
+  // K spans (g.ksplit > 1, GPT_EPI_STORE_F32 into a workspace): workgroup (span, tile) contracts its span of the K-tiles
+  const int nwg = gridDim.x / g.ksplit, span = blockIdx.x / nwg, bid = blockIdx.x - span * nwg;
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   const int tiles_n = (g.N + BN - 1) / BN;
@@ -90,7 +91,8 @@ __global__ __launch_bounds__(WM * 128, WM) void gemm_nt_kernel(GemmArgs<T> g) {
   const int m0 = tm * BM, n0 = tn * BN;
 
   constexpr int BK = ROWB / sizeof(T);
-  const int nk = g.K / BK;
+  const int nk_all = g.K / BK, nk_span = (nk_all + g.ksplit - 1) / g.ksplit, kt0 = span * nk_span;
+  const int nk = min(nk_span, nk_all - kt0);      // host: every span gets at least one K-tile
 
   // bf16: 16x16x32 MFMAs (one per 64-byte K-step and 16 x 16 tile; higher sustained clock than 32x32x16, see gemm256.hip),
   // 4 x 4 accumulator tiles;  fp32: 32x32x2, 2 x 2 tiles
@@ -113,8 +115,8 @@ __global__ __launch_bounds__(WM * 128, WM) void gemm_nt_kernel(GemmArgs<T> g) {
 
   auto stage = [&](int kt) {
     char* buf = smem + (kt % NSTAGE) * STAGE_BYTES;
-    stage_rows<T, PIECES_A>(g.A, g.lda, m0, g.M, kt * BK, buf, wid * PIECES_A, lane);
-    stage_rows<T, PIECES_W>(g.W, g.ldw, n0, g.N, kt * BK, buf + BM * ROWB, wid * PIECES_W, lane);
+    stage_rows<T, PIECES_A>(g.A, g.lda, m0, g.M, (kt0 + kt) * BK, buf, wid * PIECES_A, lane);
+    stage_rows<T, PIECES_W>(g.W, g.ldw, n0, g.N, (kt0 + kt) * BK, buf + BM * ROWB, wid * PIECES_W, lane);
   };
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
@@ -182,6 +184,14 @@ __global__ __launch_bounds__(WM * 128, WM) void gemm_nt_kernel(GemmArgs<T> g) {
         for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + 4 * fh) * PATCH_PITCH + j * 32 + fr] = acc[step][j][e];
     }
   };
+  if constexpr (EPI == GPT_EPI_STORE_F32) {
+    if (g.ksplit > 1) {
+      GemmArgs<T> ge = g;
+      ge.C = (float*)g.C + (int64_t)span * g.M * g.ldc;   // this span's slab of the workspace
+      epilogue_wave<T, EPI, 2>(ge, to_patch, patch, m0 + wr * 64, n0 + wc * 64, lane);
+      return;
+    }
+  }
   epilogue_wave<T, EPI, 2>(g, to_patch, patch, m0 + wr * 64, n0 + wc * 64, lane);
 }
 
@@ -202,7 +212,7 @@ int launch_shape(const GemmArgs<T>& g, hipStream_t s) {
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
   const bool rec = g_prof.on && g_prof.n < GemmProf::CAP;
   if (rec) (void)hipEventRecord(g_prof.ev[g_prof.n][0], s);
-  hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, WM, NSTAGE>), dim3(tiles), dim3(WM * 128), LDS, s, g);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, EPI, WM, NSTAGE>), dim3(tiles * g.ksplit), dim3(WM * 128), LDS, s, g);
   if (rec) {
     (void)hipEventRecord(g_prof.ev[g_prof.n][1], s);
     g_prof.flops[g_prof.n++] = 2.0 * g.M * g.N * g.K;
@@ -332,6 +342,29 @@ int n_cus() {
   return n_cu;
 }
 
+// The row tail of a 256-row launch (plan_rows256) is a sliver: at B = 320 fc1's is 128 rows x 6144 columns = 48 tiles of the
+// 128 x 128 ring kernel, one workgroup on 48 of the 256 CUs walking all of K alone (latency-bound: 21 us for 2.4 GFLOP).
+// With a workspace its K range is cut into spans of >= 12 ring K-tiles (384 of K) so that the tail covers the chip:
+// pass 1 stores fp32 partial tiles, pass 2 (splitk_reduce_kernel) sums them and applies the epilogue.
+template <typename T>
+int pick_tail_spans(const GemmArgs<T>& g) {
+  static const bool enabled = [] {
+    const char* e = getenv("GPT_GEMM_TAILSPLIT");   // 0 disables (A/B measurements)
+    return !e || atoi(e) != 0;
+  }();
+  const SplitWs& ws = split_ws();
+  if (!enabled || !ws.ptr || sizeof(T) != 2 || g.N % 8 != 0) return 1;
+  const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128), nk = g.K / (ROWB / (int)sizeof(T));
+  if (tiles * 2 > n_cus()) return 1;                 // the tail already gives every CU a workgroup
+  int sp = 2 * n_cus() / tiles;
+  if (sp > nk / 12) sp = nk / 12;
+  const size_t slab = (size_t)g.M * g.N * sizeof(float);
+  if ((size_t)sp * slab > ws.bytes) sp = (int)(ws.bytes / slab);
+  if (sp < 2) return 1;
+  const int per = (nk + sp - 1) / sp;
+  return (nk + per - 1) / per;
+}
+
 // cost in units of one full round of 256 x 256 tiles; *m_main = rows given to the 256 x 256 kernel (the rest: ring kernels)
 template <typename T>
 double plan_rows256(const GemmArgs<T>& g, int* m_main) {
@@ -414,6 +447,15 @@ int dispatch(const GemmArgs<T>& g, int epi, hipStream_t s) {
     tail.A = g.A + (int64_t)m_main * g.lda;
     tail.C = (char*)g.C + (int64_t)m_main * g.ldc * (c32 ? 4 : sizeof(T));
     if (g.aux) tail.aux = (char*)g.aux + (int64_t)m_main * g.ldaux * (aux32 ? 4 : sizeof(T));
+    if constexpr (sizeof(T) == 2) {
+      const int sp = pick_tail_spans(tail);
+      if (sp > 1) {
+        GemmArgs<T> part = tail;                    // pass 1: raw fp32 partial tiles of the tail rows, [sp][tail.M][N]
+        part.bias = nullptr; part.aux = nullptr; part.C = split_ws().ptr; part.ldc = g.N; part.ksplit = sp;
+        rc = launch_shape<T, GPT_EPI_STORE_F32, 2, 4>(part, s);
+        return rc != 0 ? rc : dispatch_reduce<T>(tail, epi, split_ws().ptr, sp, s);
+      }
+    }
     return dispatch_ring<T>(tail, epi, s);
   }
   return dispatch_ring<T>(g, epi, s);
