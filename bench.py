@@ -216,6 +216,20 @@ def pmc_traffic(case, B, dtype):
         return json.load(f)["traffic_bytes_per_launch"]
 
 
+def pmc_mfma_util(case, B, dtype):
+    """Fraction of the chip's matrix-pipe cycles that were busy while the GEMM kernels ran, from the PMC pass committed under
+    profiles/ (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 256 CUs x 4 SIMDs), tools/pmc_mfma.py, same command): like
+    `traffic` it cannot be read from inside the run, so it is reported for the workload it was collected on only."""
+    path = os.path.join(ROOT, "profiles", "r01_mfma_util.json")
+    if (case, B, dtype) != ("mnist", 320, "bf16") or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rows = [v for k, v in json.load(f).items() if "gemm256_kernel" in k or "gemm_nt_kernel" in k]
+    busy = sum(v["mfma_busy_cycles"] for v in rows)
+    cyc = sum(v["gui_active_cycles"] / 8.0 * 256 * 4 for v in rows)
+    return busy / cyc if cyc else None
+
+
 def sync_all(world):
     if world > 1:
         dist.barrier()
@@ -268,6 +282,7 @@ def bench_sample(args, device, world, rank):
         achieved = fl.value / (ms.value * 1e-3) / 1e12
         line["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK[args.dtype], "unit": "TFLOP/s",
                             "frac": achieved / PEAK[args.dtype], "traffic": pmc_traffic(case, B, args.dtype),
+                            "mfma_util_pmc": pmc_mfma_util(case, B, args.dtype),
                             "kernel": "gemm_nt_kernel (qkv/proj/fc1/fc2 contractions)", "launches": nl.value,
                             "avg_launch_us": ms.value * 1e3 / max(nl.value, 1),
                             "flops_per_launch": fl.value / max(nl.value, 1)}

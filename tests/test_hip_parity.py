@@ -89,7 +89,9 @@ def test_gemm_epilogues(dtype, tol, M, N, K):
     assert rel_err(out.float().cpu(), torch.nn.functional.gelu(ref)) < tol
 
 
-@pytest.mark.parametrize("M,N,K", [(1664, 1536, 6144), (1700, 1528, 6464), (3328, 1536, 4608), (520, 264, 2048)])
+@pytest.mark.parametrize("M,N,K", [(1664, 1536, 6144), (1700, 1528, 6464), (3328, 1536, 4608), (520, 264, 2048),
+                                   # one round of 256-row tiles + a 128-row tail that the ring kernel contracts in 2 K spans
+                                   (2176, 8192, 768)])
 def test_gemm_split_k_workspace(M, N, K):
     """bf16 problems of few 256 x 256 tiles and a long K go through K spans + a reduce pass once a workspace is registered
     (gpt_gemm_set_workspace): every epilogue against fp64, ragged M / N / K-span counts included, and the output after
@@ -196,7 +198,9 @@ def test_layernorm(d, out_dtype):
 
 
 @pytest.mark.parametrize("dtype,tol", [("fp32", 1e-5), ("bf16", 1.5e-2)])
-@pytest.mark.parametrize("H,hd,T", [(2, 96, 26), (2, 128, 26), (16, 96, 26), (3, 32, 18), (2, 64, 32), (1, 96, 5)])
+@pytest.mark.parametrize("H,hd,T", [(2, 96, 26), (2, 128, 26), (16, 96, 26), (3, 32, 18), (2, 64, 32), (1, 96, 5),
+                                    # T = 32 fills the per-wave LDS tile the output is staged through
+                                    (3, 96, 32), (2, 128, 32), (5, 32, 32), (1, 64, 1)])
 def test_attention(dtype, tol, H, hd, T):
     g = torch.Generator().manual_seed(H * hd + T)
     B, d = 5, H * hd
