@@ -309,6 +309,81 @@ int dispatch_reduce(const GemmArgs<T>& g, int epi, const float* part, int nspan,
   return -1;
 }
 
+// ---- residual GEMM + the LayerNorm that follows it, for small batches -----------------------------------------------------
+// x_out = resid + A W^T + bias is always followed by a LayerNorm of x_out (transformer.py:70-71: ln2 after the attention
+// projection, the next block's ln1 / ln_f after mlp.2).  When the GEMM runs in K spans anyway, pass 2 can be that LayerNorm:
+// one wave per row sums the spans, adds bias and residual, writes the fp32 row and normalises it from registers - the reduce
+// pass and the LayerNorm launch (6 us each at M = 1664) become one kernel, and the LayerNorm's re-read of x_out disappears.
+// Same arithmetic, in the same order, as splitk_reduce_kernel followed by layernorm_kernel (norm.hip): bit-identical results.
+template <int NV, typename OutT>
+__global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(const float* __restrict__ part, int nspan, const float* __restrict__ bias,
+                                                               const float* resid, int64_t ldr, float* x,   // may be the same rows
+                                                               int64_t ldx, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, OutT* __restrict__ y,
+                                                               float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows,
+                                                               float eps) {
+  constexpr int d = NV * 256;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t slab = (int64_t)rows * d;
+  const float4* pr = reinterpret_cast<const float4*>(part + (int64_t)row * d);
+  const float4* rr = reinterpret_cast<const float4*>(resid + (int64_t)row * ldr);
+  float4* xr = reinterpret_cast<float4*>(x + (int64_t)row * ldx);
+  float4 v[NV], res[NV];
+  float s = 0.f;
+  // span loop outside, the row's NV loads of one span in flight together (the other nesting serialises NV x nspan latencies)
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] = pr[lane + i * 64];
+    res[i] = rr[lane + i * 64];
+  }
+  for (int sp = 1; sp < nspan; ++sp) {
+    const float4* ps = reinterpret_cast<const float4*>(part + sp * slab + (int64_t)row * d);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = add4(v[i], ps[lane + i * 64]);
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    if (bias) v[i] = add4(v[i], reinterpret_cast<const float4*>(bias)[c]);
+    v[i] = add4(res[i], v[i]);
+    xr[c] = v[i];
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+    q += (a * a + b * b) + (c * c + e * e);
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+  OutT* yr = y + (int64_t)row * d;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    const float4 g = reinterpret_cast<const float4*>(gamma)[c], b = reinterpret_cast<const float4*>(beta)[c];
+    float4 o;
+    o.x = (v[i].x - mean) * rstd * g.x + b.x;
+    o.y = (v[i].y - mean) * rstd * g.y + b.y;
+    o.z = (v[i].z - mean) * rstd * g.z + b.z;
+    o.w = (v[i].w - mean) * rstd * g.w + b.w;
+    if constexpr (sizeof(OutT) == 4) {
+      reinterpret_cast<float4*>(yr)[c] = o;
+    } else {
+      uint2 pk;
+      pk.x = pack_bf16x2(o.x, o.y);
+      pk.y = pack_bf16x2(o.z, o.w);
+      reinterpret_cast<uint2*>(yr)[c] = pk;
+    }
+  }
+}
+
 int n_cus();
 
 // spans for a problem of `tiles` 256 x 256 tiles and nk K-tiles: fill the CUs once, keep >= 16 K-tiles per span, fit the
@@ -482,6 +557,77 @@ extern "C" int gpt_gemm_set_workspace(void* ptr, size_t bytes) {
   GPT_REQUIRE((ptr == nullptr) == (bytes == 0) && ((uintptr_t)ptr % 16) == 0, "gpt_gemm_set_workspace: need a 16-byte aligned buffer (or NULL, 0)");
   split_ws() = SplitWs{(float*)ptr, bytes};
   return 0;
+}
+
+// spans for the fused residual GEMM + LayerNorm: pass 2 replaces a LayerNorm launch that would run anyway, so shorter spans
+// pay than in pick_spans (>= 8 K-tiles of 64 instead of 16)
+static int pick_spans_ln(int M, int N, int K, int* rt) {
+  static const bool enabled = [] {
+    const char* e = getenv("GPT_GEMM_FUSELN");   // 0 disables (A/B measurements)
+    return !e || atoi(e) != 0;
+  }();
+  const SplitWs& ws = split_ws();
+  *rt = 8;
+  if (!enabled || !ws.ptr || K % 64 != 0 || tile_mode() != 0) return 1;
+  const int nk = K / 64, tn = (N + 255) / 256;
+  const int tiles256 = ((M + 255) / 256) * tn, tiles128 = ((M + 127) / 128) * tn;
+  if (tiles256 * 2 > n_cus()) return 1;
+  // long K: full-height tiles in spans of >= 16 K-tiles (the rule of pick_spans).  Short K (the attention projection: 24
+  // K-tiles): half-height tiles while they leave room for two spans, spans of >= 8 K-tiles.
+  int sp = n_cus() / tiles256;
+  if (sp > nk / 16) sp = nk / 16;
+  if (sp < 2) {
+    const int tiles = tiles128 * 2 <= n_cus() ? tiles128 : tiles256;
+    *rt = tiles == tiles128 ? 4 : 8;
+    sp = n_cus() / tiles;
+    if (sp > nk / 8) sp = nk / 8;
+  }
+  const size_t slab = (size_t)M * N * sizeof(float);
+  if ((size_t)sp * slab > ws.bytes) sp = (int)(ws.bytes / slab);
+  if (sp < 2) return 1;
+  const int per = (nk + sp - 1) / sp;
+  return (nk + per - 1) / per;
+}
+
+extern "C" int gpt_gemm_resadd_layernorm(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                                         const float* resid, int64_t ldr, float* x, int64_t ldx, const float* gamma,
+                                         const float* beta, void* y, float* mean, float* rstd, int M, int N, int K, float eps,
+                                         void* stream) {
+  GPT_REQUIRE(A && W && resid && x && gamma && beta && y, "gpt_gemm_resadd_layernorm: null operand");
+  GPT_REQUIRE(ldx == N, "gpt_gemm_resadd_layernorm: the residual stream must be dense (ldx == N)");
+  GPT_REQUIRE(ldr % 4 == 0 && ((uintptr_t)resid % 16) == 0 && ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0 &&
+                  ((uintptr_t)y % 8) == 0,
+              "gpt_gemm_resadd_layernorm: operands must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  int rt = 8;
+  const int nv = N % 256 == 0 ? N / 256 : 0;
+  const bool nv_ok = nv == 3 || nv == 4 || nv == 6 || nv == 8 || nv == 12;
+  const int sp = (dtype == GPT_BF16 && nv_ok && M > 0 && K > 0 && lda >= K && ldw >= K && ((uintptr_t)A % 16) == 0 &&
+                  ((uintptr_t)W % 16) == 0 && (lda * 2) % 16 == 0 && (ldw * 2) % 16 == 0 && ((uintptr_t)bias % 16) == 0)
+                     ? pick_spans_ln(M, N, K, &rt)
+                     : 1;
+  if (sp < 2) {
+    // large batches (and fp32): the single-pass GEMM with its residual epilogue, then the LayerNorm kernel
+    const int rc = gpt_gemm_nt(dtype, A, lda, W, ldw, bias, x, ldx, resid == x ? nullptr : (void*)resid, ldr, M, N, K,
+                               GPT_EPI_RESADD, stream);
+    return rc != 0 ? rc : gpt_layernorm(x, gamma, beta, nullptr, 0, y, dtype, mean, rstd, M, N, eps, stream);
+  }
+  GemmArgs<bf16_t> part{(const bf16_t*)A, (const bf16_t*)W, nullptr, split_ws().ptr, nullptr, lda, ldw, N, 0, M, N, K};
+  part.ksplit = sp;
+  const int rc = gemm256_bf16(part, GPT_EPI_STORE_F32, rt, s);
+  if (rc != 0) return rc;
+  const dim3 grid((M + 3) / 4), block(256);
+#define RLN(NV) hipLaunchKernelGGL((splitk_reduce_ln_kernel<NV, bf16_t>), grid, block, 0, s, split_ws().ptr, sp, bias, resid, ldr, x, \
+                                   ldx, gamma, beta, (bf16_t*)y, mean, rstd, M, eps)
+  switch (nv) {
+    case 3: RLN(3); break;
+    case 4: RLN(4); break;
+    case 6: RLN(6); break;
+    case 8: RLN(8); break;
+    default: RLN(12); break;
+  }
+#undef RLN
+  return gpt_launch_status("gpt_gemm_resadd_layernorm");
 }
 
 extern "C" int gpt_gemm_prof_enable(int on) {

@@ -73,6 +73,10 @@ static int denoiser_forward(const gpt_model_t* m, const gpt_workspace_t* ws, con
   // ln_in + position embedding (transformer.py:226, 308-309)
   CHECK(gpt_layernorm(ws->enc, m->ln_in_w, m->ln_in_b, m->pos_emb, T, xbuf(0), GPT_F32, stat(0, 0), stat(0, 1), M, d, 1e-5f, stream));
 
+  // Every residual Linear is launched together with the LayerNorm that reads its result (gpt_gemm_resadd_layernorm: one
+  // fused pass at small batches, the two kernels otherwise): proj + ln2, mlp.2 + the next block's ln1 (ln_f after the last).
+  CHECK(gpt_layernorm(xbuf(0), m->layers[0].ln1_w, m->layers[0].ln1_b, nullptr, 0, lay(ws->h1, 0, d), dt, stat(1, 0), stat(1, 1), M, d,
+                      1e-5f, stream));
   for (int l = 0; l < L; ++l) {
     const gpt_layer_t& ly = m->layers[l];
     float* xin = xbuf(2 * l);
@@ -83,22 +87,26 @@ static int denoiser_forward(const gpt_model_t* m, const gpt_workspace_t* ws, con
     void* att = lay(ws->att, l, d);
     void* h2 = lay(ws->h2, l, d);
     void* act = lay(ws->act, l, 4 * (size_t)d);
-    CHECK(gpt_layernorm(xin, ly.ln1_w, ly.ln1_b, nullptr, 0, h1, dt, stat(1 + 2 * l, 0), stat(1 + 2 * l, 1), M, d, 1e-5f, stream));
     CHECK(gpt_gemm_nt(dt, h1, d, ly.wqkv, d, ly.bqkv, qkv, 3 * d, nullptr, 0, M, 3 * d, d, GPT_EPI_STORE, stream));
     CHECK(gpt_attention(dt, qkv, att, B, T, m->n_head, d / m->n_head, stream));
-    CHECK(gpt_gemm_nt(dt, att, d, ly.wproj, d, ly.bproj, xmid, d, keep ? xin : nullptr, d, M, d, d, GPT_EPI_RESADD, stream));
-    CHECK(gpt_layernorm(xmid, ly.ln2_w, ly.ln2_b, nullptr, 0, h2, dt, stat(2 + 2 * l, 0), stat(2 + 2 * l, 1), M, d, 1e-5f, stream));
+    CHECK(gpt_gemm_resadd_layernorm(dt, att, d, ly.wproj, d, ly.bproj, xin, d, xmid, d, ly.ln2_w, ly.ln2_b, h2, stat(2 + 2 * l, 0),
+                                    stat(2 + 2 * l, 1), M, d, d, 1e-5f, stream));
     if (keep) {
       void* pre = lay(ws->pre, l, 4 * (size_t)d);
       CHECK(gpt_gemm_nt(dt, h2, d, ly.w1, d, ly.b1, act, 4 * d, pre, 4 * d, M, 4 * d, d, GPT_EPI_GELU_AUX, stream));
     } else {
       CHECK(gpt_gemm_nt(dt, h2, d, ly.w1, d, ly.b1, act, 4 * d, nullptr, 0, M, 4 * d, d, GPT_EPI_GELU, stream));
     }
-    CHECK(gpt_gemm_nt(dt, act, 4 * d, ly.w2, 4 * d, ly.b2, xout, d, keep ? xmid : nullptr, d, M, d, 4 * d, GPT_EPI_RESADD, stream));
+    // (Pruning the rows of the tokens the decoder does not read after the last block's attention was built and measured in
+    // r01: no gain at B = 320 - the compacted 3520-row GEMMs fall to the slower small-problem kernels.)
+    const bool last = l + 1 == L;
+    const float* nw = last ? m->ln_f_w : m->layers[l + 1].ln1_w;
+    const float* nb = last ? m->ln_f_b : m->layers[l + 1].ln1_b;
+    void* nh = last ? ws->hf : lay(ws->h1, l + 1, d);
+    const int ns = last ? 2 * L + 1 : 1 + 2 * (l + 1);
+    CHECK(gpt_gemm_resadd_layernorm(dt, act, 4 * d, ly.w2, 4 * d, ly.b2, xmid, d, xout, d, nw, nb, nh, stat(ns, 0), stat(ns, 1), M, d,
+                                    4 * d, 1e-5f, stream));
   }
-  // (Pruning the rows of the tokens the decoder does not read after the last block's attention was built and measured in
-  // r01: no gain at B = 320 - the compacted 3520-row GEMMs fall to the slower small-problem kernels.)
-  CHECK(gpt_layernorm(xbuf(2 * L), m->ln_f_w, m->ln_f_b, nullptr, 0, ws->hf, dt, stat(2 * L + 1, 0), stat(2 * L + 1, 1), M, d, 1e-5f, stream));
   CHECK(gpt_decode_tokens(dt, m->n_out_tok, ws->hf, T, m->dec_w, m->dec_n, m->dec_off, x_prev, out, B, d, m->D, stream));
   return 0;
 }

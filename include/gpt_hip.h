@@ -55,6 +55,19 @@ int gpt_gemm_nt(int dtype, const void* A, int64_t lda, const void* W, int64_t ld
  * 64 MiB covers the G.pt shapes.  (NULL, 0) unregisters.  No counterpart in the reference (an ATen/cuBLAS internal). */
 int gpt_gemm_set_workspace(void* ptr, size_t bytes);
 
+/* The residual Linear of a Block together with the LayerNorm that reads its result (Gpt/models/transformer.py:70-71:
+ * x = x + attn(ln1(x)); then ln2(x) - and x = x + mlp(ln2(x)); then the next block's ln1 or ln_f, :311):
+ *   x[M,N] (fp32, dense: ldx == N) = resid[M,N] (fp32, leading dim ldr; may be x itself) + A[M,K] . W[N,K]^T + bias
+ *   y[M,N] (dtype)                 = LayerNorm(x; gamma, beta, eps);   mean / rstd (fp32 per row) optional
+ * Exactly gpt_gemm_nt(..., GPT_EPI_RESADD) followed by gpt_layernorm, and for large problems run as those two kernels.
+ * Small bf16 problems (few output tiles) with a workspace registered are contracted in K spans, and the pass that sums the
+ * spans is the LayerNorm: one kernel less per residual Linear and no re-read of x.  N must be 768, 1024, 1536, 2048 or
+ * 3072 for that path; other shapes take the two-kernel route. */
+int gpt_gemm_resadd_layernorm(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                              const float* resid, int64_t ldr, float* x, int64_t ldx, const float* gamma,
+                              const float* beta, void* y, float* mean, float* rstd, int M, int N, int K, float eps,
+                              void* stream);
+
 /* C[I, J] (+)= P[R, I]^T . Q[R, J]: bf16 operands contracted over their ROW index, fp32 output (accumulate != 0:
  * C += ...).  The weight gradient dW = dY^T . X that autograd derives for every nn.Linear of the trunk
  * (Gpt/models/transformer.py:38-40, 50, 63-65), reading dY [B*T, n_out] and X [B*T, k_in] as they lie in memory

@@ -148,6 +148,50 @@ def test_gemm_split_k_workspace(M, N, K):
     L._gemm_ws.pop(torch.device(DEV).index, None)     # the engines' registration was replaced above: let them renew it
 
 
+@pytest.mark.parametrize("M,N,K,inplace", [(1664, 1536, 1536, True), (1664, 1536, 6144, False), (3328, 1536, 1536, False),
+                                            (1700, 2048, 2048, True), (8320, 1536, 1536, True), (520, 264, 2048, False)])
+def test_gemm_resadd_layernorm(M, N, K, inplace):
+    """Residual Linear + the LayerNorm behind it in one call: against fp64, and against the two separate entry points (the
+    fused K-span pass at small batches, the two-kernel route at M = 8320 and for widths the fused pass does not cover)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
+    bias, R = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    gam, bet = 1 + 0.1 * torch.randn(N, generator=g), 0.1 * torch.randn(N, generator=g)
+    Ad, Wd = A.to(DEV).bfloat16(), W.to(DEV).bfloat16()
+    xref = R.double() + Ad.float().cpu().double() @ Wd.float().cpu().double().t() + bias.double()
+    yref = torch.nn.functional.layer_norm(xref, (N,), gam.double(), bet.double(), 1e-5)
+    lib, bias_d, gd, bd = L.lib(), bias.to(DEV), gam.to(DEV), bet.to(DEV)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    try:
+        L.check(lib.gpt_gemm_set_workspace(L.ptr(ws), ws.numel()), "ws")
+        res = R.to(DEV).clone()
+        x = res if inplace else torch.empty(M, N, device=DEV)
+        y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+        L.check(lib.gpt_gemm_resadd_layernorm(L.BF16, L.ptr(Ad), K, L.ptr(Wd), K, L.ptr(bias_d), L.ptr(res), N, L.ptr(x), N,
+                                              L.ptr(gd), L.ptr(bd), L.ptr(y), L.ptr(mean), L.ptr(rstd), M, N, K, 1e-5,
+                                              L.stream()), "fused")
+        torch.cuda.synchronize()
+        assert rel_err(x.cpu(), xref) < 1e-4                       # fp32 partials, fp32 residual stream
+        assert rel_err(y.float().cpu(), yref) < 1e-2
+        np.testing.assert_allclose(mean.cpu().numpy(), xref.mean(1).numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(rstd.cpu().numpy(), (1 / torch.sqrt(xref.var(1, unbiased=False) + 1e-5)).numpy(), rtol=1e-4)
+        # the two entry points it stands for
+        x2 = R.to(DEV).clone()
+        y2 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        L.check(lib.gpt_gemm_nt(L.BF16, L.ptr(Ad), K, L.ptr(Wd), K, L.ptr(bias_d), L.ptr(x2), N, None, 0, M, N, K, L.EPI_RESADD,
+                                L.stream()), "gemm")
+        L.check(lib.gpt_layernorm(L.ptr(x2), L.ptr(gd), L.ptr(bd), None, 0, L.ptr(y2), L.BF16, None, None, M, N, 1e-5,
+                                  L.stream()), "ln")
+        torch.cuda.synchronize()
+        assert rel_err(x.cpu(), x2.cpu().double()) < 1e-5
+        dy = (y.float() - y2.float()).abs()
+        assert bool((dy <= y2.float().abs() * 2.0 ** -7 + 1e-3).all()), float(dy.max())
+    finally:
+        L.check(lib.gpt_gemm_set_workspace(None, 0), "ws")
+        L._gemm_ws.pop(torch.device(DEV).index, None)
+
+
 def test_gemm_gelu_bf16_range():
     """bf16 GELU epilogue (x * sigmoid(fitted odd polynomial)) against the exact erf GELU over [-30, 30], outliers included:
     error <= one bf16 rounding of the result + 2.6e-5 (the fit's bound, gemm_common.h)."""

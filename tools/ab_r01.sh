@@ -1,4 +1,7 @@
-G="python tools/gemm_bench.py --shapes qkv:8320:4608:1536 fc2:8320:1536:6144:2 sq8192:8192:8192:8192"
-for v in "GPT_GEMM_P=0" "GPT_GEMM_P=1" "GPT_GEMM_P=1 GPT_P_DBG=1" "GPT_GEMM_P=1 GPT_P_DBG=2"; do
-  echo "== $v"; env $v GPT_GEMM_224=0 timeout -k 10 100 $G 2>&1 | grep -v amdgpu.ids
-done
+set -e
+run() { echo "== $*"; env "$@" | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d.get('value'))"; }
+B="python bench.py --steps 150 --warmup 20 --no-cpu-baseline --no-train --no-roofline"
+run GPT_GEMM_FUSELN=0 timeout -k 10 120 $B --batch 64
+run GPT_GEMM_FUSELN=1 timeout -k 10 120 $B --batch 64
+run GPT_GEMM_FUSELN=0 timeout -k 10 120 python bench.py --mode train --batch 128 --steps 20 --warmup 5 --no-cpu-baseline
+run GPT_GEMM_FUSELN=1 timeout -k 10 120 python bench.py --mode train --batch 128 --steps 20 --warmup 5 --no-cpu-baseline
