@@ -73,10 +73,31 @@ __device__ __forceinline__ float gelu_fast_grad(float x) {
   const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
   return fmaf(x, pdf, cdf);
 }
+// The same function on a pair of elements with packed fp32 VALU (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two elements
+// per issue slot).  The GELU epilogue is VALU-bound (128 elements per lane after every tile, no MFMA beside it): per element
+// 6 single + exp + rcp issue slots become 3 packed + min + exp + rcp.  The range guard moves from x (v_med3) to x^2
+// (min(x^2, 64)): beyond |x| = 8 the exponent is then x * P(64) = -4.98 x, which saturates the sigmoid to 0 / 1 like the clamp
+// did (2^40 and up, or inf: rcp gives 0) - identical results inside the range, covered by test_gemm_gelu_bf16_range outside.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+  constexpr float A = -1.5950157686361435f * 1.4426950408889634f, B = -0.07401129203229191f * 1.4426950408889634f,
+                  Cc = 0.000703033580348536f * 1.4426950408889634f;
+  f32x2 x2 = x * x;
+  x2.x = fminf(x2.x, 64.0f);
+  x2.y = fminf(x2.y, 64.0f);
+  const f32x2 p = __builtin_elementwise_fma(x2, __builtin_elementwise_fma(x2, f32x2{Cc, Cc}, f32x2{B, B}), f32x2{A, A});
+  const f32x2 q = x * p;
+  const f32x2 e = f32x2{__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)} + f32x2{1.0f, 1.0f};
+  return x * f32x2{__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+}
 template <typename T>
 __device__ __forceinline__ float4 gelu4(const float4& v) {
-  if constexpr (sizeof(T) == 4) return make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
-  else return make_float4(gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w));
+  if constexpr (sizeof(T) == 4) {
+    return make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+  } else {
+    const f32x2 a = gelu_fast2(f32x2{v.x, v.y}), b = gelu_fast2(f32x2{v.z, v.w});
+    return make_float4(a.x, a.y, b.x, b.y);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
