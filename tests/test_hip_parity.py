@@ -395,6 +395,32 @@ def test_p_sample_loop_golden(golden, case, resp, tag, px, clip):
         assert torch.isfinite(outs[-1]["sample"]).all()
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_sampled_mlp_downstream_loss_within_1pct(golden, dtype):
+    """north_star check 2, on the surrogate SURVEY.md 8c allows (no pretrained weights / MNIST offline): MNIST-MLP parameter
+    vectors sampled by the HIP path (same weights, prompts and injected noise as the reference's 50-step trajectory of
+    fixture g7) must score a downstream test loss within 1 % of the loss of the REFERENCE's samples, in the fp32 and in the
+    bf16 denoiser.  Scored by the batched MLP evaluator (pinned by fixture g10) on g10's 64 synthetic images, after the
+    reference's un-normalisation (/ 4.185, Gpt/data/normalization.py:27-29)."""
+    g = golden("g7_sampling_mnist_small_r50")
+    ev = golden("g10_mlp_eval")
+    m, plan, sd = build("mnist_small", dtype)
+    diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000,
+                                    timestep_respacing="50")
+    n, B = diff.num_timesteps, 3
+    _, _, lt, lp, xp = make_inputs("mnist_small", B=B, seed=31)
+    noise = torch.stack([step_noise(1234, i, B, plan.D) for i in range(n)])
+    kw = dict(loss_target=lt.to(DEV), loss_prev=lp.to(DEV), x_prev=xp.to(DEV))
+    got = diff.p_sample_loop(m, (B, plan.D), noise=step_noise(1234, -1, B, plan.D).to(DEV), clip_denoised=False,
+                             model_kwargs=kw, device="cuda", step_noise=noise)
+    imgs, labels = torch.from_numpy(ev["imgs"]).to(DEV), torch.from_numpy(ev["labels"]).to(DEV)
+    ref = torch.from_numpy(g["sample_at_0"]).to(DEV)
+    loss_ref, _ = gpt_amd.mlp_test_losses(ref / 4.185, imgs, labels)
+    loss_got, _ = gpt_amd.mlp_test_losses(got / 4.185, imgs, labels)
+    rel = ((loss_got - loss_ref).abs() / loss_ref).max().item()
+    assert rel < 1e-2, (rel, loss_got.tolist(), loss_ref.tolist())
+
+
 @pytest.mark.parametrize("case,resp,tag,eta,px,clip", [
     ("mnist_small", "ddim25", "ddim25_eta0", 0.0, True, False), ("mnist_small", "50", "r50_eta05", 0.5, True, False),
     ("cifar_small", "ddim25", "ddim25_eta1_eps_clip", 1.0, False, True)])
