@@ -514,6 +514,34 @@ def test_sampling_properties_full_size():
     assert torch.equal(full, x)
 
 
+@pytest.mark.parametrize("dtype,bar", [("fp32", 1e-3), ("bf16", 1e-2)])
+def test_full_size_sampling_vs_oracle_and_downstream_loss(golden, dtype, bar):
+    """The pretrained mnist_loss shapes (d = 1536, 12 layers, D = 7960): a 10-step respaced p_sample_loop with injected noise
+    on the HIP path against the oracle's loop on the host.  fp32: sampled vectors within 1e-3 (north_star check 1 carried
+    through the whole loop); both dtypes: downstream MLP test loss of the samples within 1 % of the oracle's (check 2)."""
+    m, plan, sd = build("mnist", dtype, seed=2)
+    diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000,
+                                    timestep_respacing="10")
+    tb = odf.Tables(1000, "10")
+    B, n = 4, diff.num_timesteps
+    _, _, lt, lp, xp = make_inputs("mnist", B=B, seed=12)
+    start = step_noise(77, -1, B, plan.D)
+    noise = torch.stack([step_noise(77, i, B, plan.D) for i in range(n)])
+    with torch.no_grad():
+        ref = odf.p_sample_loop(tb, lambda x, t: od.forward(sd, plan, x, t, lt, lp, xp), start, lambda i: noise[i])
+    kw = dict(loss_target=lt.to(DEV), loss_prev=lp.to(DEV), x_prev=xp.to(DEV))
+    got = diff.p_sample_loop(m, (B, plan.D), noise=start.to(DEV), clip_denoised=False, model_kwargs=kw, device="cuda",
+                             step_noise=noise)
+    if dtype == "fp32":
+        assert rel_err(got.cpu(), ref.double()) < bar
+    ev = golden("g10_mlp_eval")
+    imgs, labels = torch.from_numpy(ev["imgs"]).to(DEV), torch.from_numpy(ev["labels"]).to(DEV)
+    loss_ref, _ = gpt_amd.mlp_test_losses(ref.to(DEV) / 4.185, imgs, labels)
+    loss_got, _ = gpt_amd.mlp_test_losses(got / 4.185, imgs, labels)
+    rel = ((loss_got - loss_ref).abs() / loss_ref).max().item()
+    assert rel < 1e-2, (rel, loss_got.tolist(), loss_ref.tolist())
+
+
 # ------------------------------------------------------------------------------------------ permutation
 def test_permutation_maps_bit_exact(golden):
     g = golden("g8_permute")
