@@ -307,6 +307,34 @@ def test_forward_full_size_vs_oracle(case):
     assert float((out16 - ref).abs().max()) / scale < 3e-2
 
 
+@pytest.mark.parametrize("sizes,policy,chunk,absolute,n_embd,n_head", [
+    ([7840, 10, 100, 10], "layer_by_layer", None, True, 128, 4),     # 12 tokens, one of them 7840 wide (the cartpole policy)
+    ([432, 4608, 320, 10], "chunk_within_input", 1000, False, 192, 2),  # delta-loss conditioning only: 2 scalar tokens
+    ([7840, 10, 100, 10], "chunk", 1990, True, 128, 2),                 # 'chunk': 1990 divides D = 7960, nothing straddles x | x_prev
+    ([64, 8, 24], "layer_by_layer", None, True, 64, 2)])                # a tiny net: every token narrower than a K chunk
+def test_forward_other_split_policies_vs_oracle(sizes, policy, chunk, absolute, n_embd, n_head):
+    """Gpt.forward under the reference's other tokenisation policies (GPT.build_splits, transformer.py:251-300) and with
+    delta-only loss conditioning: HIP fp32 path against the oracle (pinned for the token plans by fixture g1)."""
+    names = [f"p{i}" for i in range(len(sizes))]
+    plan = od.Plan(sizes, 128, 14, absolute, n_head, n_embd, 2, chunk, policy, True)
+    sd = od.random_state_dict(plan, seed=4)
+    m = gpt_amd.Gpt(parameter_sizes=list(sizes), parameter_names=names, num_frequencies=128, max_freq_log2=14, predict_xstart=True,
+                    absolute_loss_conditioning=absolute, n_embd=n_embd, n_head=n_head, n_layer=2, chunk_size=chunk,
+                    split_policy=policy, encoder_depth=1, decoder_depth=1, attn_pdrop=0.0, resid_pdrop=0.0, embd_pdrop=0.0)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval().set_compute_dtype("fp32")
+    D, B = sum(sizes), 5
+    g = torch.Generator().manual_seed(D)
+    xp, x = torch.randn(B, D, generator=g) * 0.5, torch.randn(B, D, generator=g)
+    t = torch.tensor([999, 0, 1, 500, 37])
+    lp, lt = 0.3 + 2 * torch.rand(B, generator=g), torch.zeros(B)
+    with torch.no_grad():
+        ref = od.forward(sd, plan, x, t, lt, lp, xp)
+        got = m(x.to(DEV), t.to(DEV), lt.to(DEV), loss_prev=lp.to(DEV), x_prev=xp.to(DEV)).cpu()
+    assert got.shape == (B, D)
+    assert float((got - ref).abs().max()) / float((ref - xp).abs().max()) < 1e-3
+
+
 @pytest.mark.parametrize("case", ["mnist_small", "cifar_small"])
 def test_forward_oracle_bf16(case):
     m, plan, sd = build(case, "bf16", seed=3)
