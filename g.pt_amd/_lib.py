@@ -60,6 +60,7 @@ _PROTOS = {
     "gpt_gemm_nt": ([i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp], i32),
     "gpt_gemm_set_workspace": ([vp, C.c_size_t], i32),
     "gpt_gemm_tn": ([vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp], i32),
+    "gpt_gemm_tn_grouped": ([i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp], i32),
     "gpt_gemm_prof_enable": ([i32], i32),
     "gpt_gemm_prof_collect": ([C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)], i32),
     "gpt_gemm_resadd_layernorm": ([i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp], i32),

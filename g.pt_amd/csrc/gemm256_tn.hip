@@ -42,15 +42,34 @@ __device__ __forceinline__ u32x4 tr_frag(const char* base, int kk) {
 // and every workgroup ADDS its partial tile with hardware fp32 atomics (one accumulator register = two full 128-byte
 // lines per wave instruction).  A weight gradient has few output tiles (d x d: 36, d x 4d: 144 on 256 CUs) and a very
 // long contraction (R = B*T rows), so spans fill the chip for the price of the atomics (~0.2 us per partial tile).
+// GROUPED launches: up to 4 independent problems with the same contraction length share one grid (workgroups [off[p], off[p+1])
+// belong to problem p).  The four weight gradients of a Block (qkv, proj, mlp.0, mlp.2) have 108 + 36 + 144 + 144 = 432 tiles at
+// d = 1536: launched one by one each leaves CUs idle (144 tiles on 256 CUs) or pays atomics for spans; together they are two
+// nearly full rounds of whole contractions, no atomics (B = 128: 4 x 85 us -> see DESIGN.md).
+constexpr int TN_MAX_GROUP = 4;
+struct TnGroup {
+  GemmArgs<bf16_t> g[TN_MAX_GROUP];
+  int off[TN_MAX_GROUP + 1];
+  int n, ksplit;
+};
+
 template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(GemmArgs<bf16_t> g, int ksplit) {
+__global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(TnGroup grp) {
   using T = bf16_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
 
-  const int nwg = gridDim.x / ksplit, span = blockIdx.x / nwg, bid = blockIdx.x - span * nwg;
+  // this workgroup's problem (workgroup-uniform selects: no dynamic indexing of the kernel argument)
+  GemmArgs<bf16_t> g = grp.g[0];
+  int wg0 = 0;
+  if (grp.n > 1 && (int)blockIdx.x >= grp.off[1]) { g = grp.g[1]; wg0 = grp.off[1]; }
+  if (grp.n > 2 && (int)blockIdx.x >= grp.off[2]) { g = grp.g[2]; wg0 = grp.off[2]; }
+  if (grp.n > 3 && (int)blockIdx.x >= grp.off[3]) { g = grp.g[3]; wg0 = grp.off[3]; }
+  const int ksplit = grp.ksplit;
+  const int local = (int)blockIdx.x - wg0;
+  const int nwg = (g.M / 256) * (g.N / 256), span = local / nwg, bid = local - span * nwg;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
   const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   // column groups of 8 tiles, rows fastest across the group (see gemm256.hip): both strips re-used from the XCD's L2
@@ -216,8 +235,30 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(GemmArgs<bf16_t> g, 
     }
 }
 
+// spans: estimated time (us) = rounds x (K-tiles per span x 1.5 + 10) + atomics at ~0.2 us per partial tile and CU round
+int pick_tn_spans(int tiles, int nk_all) {
+  static const int n_cu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  static const int forced = [] {
+    const char* e = getenv("GPT_TN_KSPLIT");   // experiments: force a span count (0 = model)
+    return e ? atoi(e) : 0;
+  }();
+  if (forced > 0) return forced;
+  int ksplit = 1;
+  double best = 1e30;
+  for (int sp = 1; sp <= 16 && sp * 8 <= nk_all; ++sp) {
+    const int wgs = tiles * sp, rounds = (wgs + n_cu - 1) / n_cu, per = (nk_all + sp - 1) / sp;
+    const double t = rounds * (per * 1.5 + 10.0) + (sp > 1 ? 0.2 * wgs : 0.0);
+    if (t < best) { best = t; ksplit = sp; }
+  }
+  return ksplit;
+}
+
 template <int EPI>
-int launch_tn(const GemmArgs<bf16_t>& g, hipStream_t s) {
+int launch_tn(TnGroup& grp, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)gemm256_tn_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, TLDS_BYTES) !=
@@ -227,34 +268,21 @@ int launch_tn(const GemmArgs<bf16_t>& g, hipStream_t s) {
     }
     attr_set = true;
   }
-  const int tiles = (g.M / 256) * (g.N / 256);
-  // spans: estimated time (us) = rounds x (K-tiles per span x 1.5 + 10) + atomics at ~0.2 us per partial tile and CU round
-  int ksplit = 1;
-  if (EPI == GPT_EPI_ACCUM_F32) {
-    static const int n_cu = [] {
-      int dev = 0, n = 256;
-      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-      return n > 0 ? n : 256;
-    }();
-    static const int forced = [] {
-      const char* e = getenv("GPT_TN_KSPLIT");   // experiments: force a span count (0 = model)
-      return e ? atoi(e) : 0;
-    }();
-    const int nk_all = g.K / 64;
-    double best = 1e30;
-    for (int sp = 1; sp <= 16 && sp * 8 <= nk_all; ++sp) {
-      const int wgs = tiles * sp, rounds = (wgs + n_cu - 1) / n_cu, per = (nk_all + sp - 1) / sp;
-      const double t = rounds * (per * 1.5 + 10.0) + (sp > 1 ? 0.2 * wgs : 0.0);
-      if (t < best) { best = t; ksplit = sp; }
-    }
-    if (forced > 0) ksplit = forced;
+  int tiles = 0;
+  double flops = 0;
+  for (int p = 0; p < grp.n; ++p) {
+    tiles += (grp.g[p].M / 256) * (grp.g[p].N / 256);
+    flops += 2.0 * grp.g[p].M * grp.g[p].N * grp.g[p].K;
   }
+  grp.ksplit = EPI == GPT_EPI_ACCUM_F32 ? pick_tn_spans(tiles, grp.g[0].K / 64) : 1;   // spans add with atomics: accumulating only
+  grp.off[0] = 0;
+  for (int p = 0; p < grp.n; ++p) grp.off[p + 1] = grp.off[p] + (grp.g[p].M / 256) * (grp.g[p].N / 256) * grp.ksplit;
   const bool rec = g_prof.on && g_prof.n < GemmProf::CAP;
   if (rec) (void)hipEventRecord(g_prof.ev[g_prof.n][0], s);
-  hipLaunchKernelGGL((gemm256_tn_kernel<EPI>), dim3(tiles * ksplit), dim3(512), TLDS_BYTES, s, g, ksplit);
+  hipLaunchKernelGGL((gemm256_tn_kernel<EPI>), dim3(grp.off[grp.n]), dim3(512), TLDS_BYTES, s, grp);
   if (rec) {
     (void)hipEventRecord(g_prof.ev[g_prof.n][1], s);
-    g_prof.flops[g_prof.n++] = 2.0 * g.M * g.N * g.K;
+    g_prof.flops[g_prof.n++] = flops;
   }
   return gpt_launch_status("gpt_gemm_tn");
 }
@@ -262,14 +290,31 @@ int launch_tn(const GemmArgs<bf16_t>& g, hipStream_t s) {
 }  // namespace
 }  // namespace gemmk
 
-extern "C" int gpt_gemm_tn(const void* P, int64_t ldp, const void* Q, int64_t ldq, float* C, int64_t ldc, int I, int J, int R,
-                           int accumulate, void* stream) {
-  using namespace gemmk;
+static int tn_check(const void* P, int64_t ldp, const void* Q, int64_t ldq, const float* C, int64_t ldc, int I, int J, int R) {
   GPT_REQUIRE(P && Q && C, "gpt_gemm_tn: null operand");
   GPT_REQUIRE(I > 0 && J > 0 && R > 0 && I % 256 == 0 && J % 256 == 0 && R % 64 == 0,
               "gpt_gemm_tn: need I %% 256 == 0, J %% 256 == 0, R %% 64 == 0 (got I=%d J=%d R=%d)", I, J, R);
   GPT_REQUIRE(ldp >= I && ldq >= J && ldc >= J && ldp % 8 == 0 && ldq % 8 == 0 && ldc % 4 == 0, "gpt_gemm_tn: bad leading dimensions");
   GPT_REQUIRE(((uintptr_t)P % 16) == 0 && ((uintptr_t)Q % 16) == 0 && ((uintptr_t)C % 16) == 0, "gpt_gemm_tn: operands must be 16-byte aligned");
-  GemmArgs<bf16_t> g{(const bf16_t*)P, (const bf16_t*)Q, nullptr, C, nullptr, ldp, ldq, ldc, 0, I, J, R};
-  return accumulate ? launch_tn<GPT_EPI_ACCUM_F32>(g, (hipStream_t)stream) : launch_tn<GPT_EPI_STORE_F32>(g, (hipStream_t)stream);
+  return 0;
+}
+
+extern "C" int gpt_gemm_tn(const void* P, int64_t ldp, const void* Q, int64_t ldq, float* C, int64_t ldc, int I, int J, int R,
+                           int accumulate, void* stream) {
+  return gpt_gemm_tn_grouped(1, &P, &ldp, &Q, &ldq, &C, &ldc, &I, &J, R, accumulate, stream);
+}
+
+extern "C" int gpt_gemm_tn_grouped(int n, const void* const* P, const int64_t* ldp, const void* const* Q, const int64_t* ldq,
+                                   float* const* C, const int64_t* ldc, const int* I, const int* J, int R, int accumulate,
+                                   void* stream) {
+  using namespace gemmk;
+  GPT_REQUIRE(n >= 1 && n <= TN_MAX_GROUP && P && ldp && Q && ldq && C && ldc && I && J, "gpt_gemm_tn_grouped: need 1..%d problems", TN_MAX_GROUP);
+  TnGroup grp;
+  grp.n = n;
+  for (int p = 0; p < n; ++p) {
+    const int rc = tn_check(P[p], ldp[p], Q[p], ldq[p], C[p], ldc[p], I[p], J[p], R);
+    if (rc != 0) return rc;
+    grp.g[p] = GemmArgs<bf16_t>{(const bf16_t*)P[p], (const bf16_t*)Q[p], nullptr, C[p], nullptr, ldp[p], ldq[p], ldc[p], 0, I[p], J[p], R};
+  }
+  return accumulate ? launch_tn<GPT_EPI_ACCUM_F32>(grp, (hipStream_t)stream) : launch_tn<GPT_EPI_STORE_F32>(grp, (hipStream_t)stream);
 }

@@ -236,6 +236,11 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
   }
 
   // stages 1 .. L - the blocks, last to first (stage s = layer L - s)
+  // When the TN kernel takes all four weight gradients of a Block they are launched TOGETHER (gpt_gemm_tn_grouped) once the last
+  // of their operands (d_qkv) exists: 432 tiles at d = 1536 = two nearly full rounds of whole contractions instead of four
+  // launches of 36 ... 144 tiles.  Until then mlp.2's dY must survive the LayerNorm backward that would overwrite it: that
+  // LayerNorm writes its operand copy to bw->tA (the NT fallback's transpose scratch, [4d, Mp] >= [M, d], unused on this path).
+  const bool grouped = use_tn && dt == GPT_BF16 && M % 64 == 0 && d % 256 == 0;
   for (int l = L - 1; l >= 0; --l) {
     if (L - l < stage_begin || L - l >= stage_end) continue;
     const gpt_layer_t& ly = m->layers[l];
@@ -246,24 +251,35 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
     const void* h2 = lay(ws->h2, l, d);
     const void* act = lay(ws->act, l, 4 * (size_t)d);
     void* pre = lay(ws->pre, l, 4 * (size_t)d);
+    void* gt2 = grouped ? bw->tA : bw->gt;               // dY of the attention projection
     // mlp.2
     CHECK(gpt_colsum(dt, bw->gt, d, gl.g_b2, M, d, stream));
-    CHECK(wgrad(bw->gt, d, act, 4 * d, gl.g_w2));
+    if (!grouped) CHECK(wgrad(bw->gt, d, act, 4 * d, gl.g_w2));
     CHECK(gpt_gemm_nt(dt, bw->gt, d, gl.w2_t, d, nullptr, bw->d_act, 4 * d, pre, 4 * d, M, 4 * d, d, GPT_EPI_DGELU, stream));
     // mlp.0
     CHECK(gpt_colsum(dt, bw->d_act, 4 * d, gl.g_b1, M, 4 * d, stream));
-    CHECK(wgrad(bw->d_act, 4 * d, h2, d, gl.g_w1));
+    if (!grouped) CHECK(wgrad(bw->d_act, 4 * d, h2, d, gl.g_w1));
     CHECK(gpt_gemm_nt(dt, bw->d_act, 4 * d, gl.w1_t, 4 * d, nullptr, bw->d_h, d, nullptr, 0, M, d, 4 * d, GPT_EPI_STORE, stream));
-    CHECK(gpt_layernorm_bwd(bw->d_h, dt, xbuf(2 * l + 1), stat(2 + 2 * l, 0), stat(2 + 2 * l, 1), ly.ln2_w, bw->g, bw->g, bw->gt, dt,
+    CHECK(gpt_layernorm_bwd(bw->d_h, dt, xbuf(2 * l + 1), stat(2 + 2 * l, 0), stat(2 + 2 * l, 1), ly.ln2_w, bw->g, bw->g, gt2, dt,
                             gl.g_ln2_w, gl.g_ln2_b, M, d, stream));
     // attention output projection
-    CHECK(gpt_colsum(dt, bw->gt, d, gl.g_bproj, M, d, stream));
-    CHECK(wgrad(bw->gt, d, att, d, gl.g_wproj));
-    CHECK(gpt_gemm_nt(dt, bw->gt, d, gl.wproj_t, d, nullptr, bw->d_h, d, nullptr, 0, M, d, d, GPT_EPI_STORE, stream));
+    CHECK(gpt_colsum(dt, gt2, d, gl.g_bproj, M, d, stream));
+    if (!grouped) CHECK(wgrad(gt2, d, att, d, gl.g_wproj));
+    CHECK(gpt_gemm_nt(dt, gt2, d, gl.wproj_t, d, nullptr, bw->d_h, d, nullptr, 0, M, d, d, GPT_EPI_STORE, stream));
     CHECK(gpt_attention_bwd(dt, qkv, bw->d_h, bw->d_qkv, B, T, m->n_head, d / m->n_head, stream));
     // query | key | value
     CHECK(gpt_colsum(dt, bw->d_qkv, 3 * d, gl.g_bqkv, M, 3 * d, stream));
-    CHECK(wgrad(bw->d_qkv, 3 * d, h1, d, gl.g_wqkv));
+    if (grouped) {
+      // mlp.2, mlp.0 first: they are the whole first round (2 x 144 tiles at d = 1536)
+      const void* P[4] = {bw->gt, bw->d_act, bw->d_qkv, gt2};
+      const void* Q[4] = {act, h2, h1, att};
+      float* Cg[4] = {gl.g_w2, gl.g_w1, gl.g_wqkv, gl.g_wproj};
+      const int I[4] = {d, 4 * d, 3 * d, d}, J[4] = {4 * d, d, d, d};
+      const int64_t ldp[4] = {d, 4 * d, 3 * d, d}, ldq[4] = {4 * d, d, d, d}, ldc[4] = {4 * d, d, d, d};
+      CHECK(gpt_gemm_tn_grouped(4, P, ldp, Q, ldq, Cg, ldc, I, J, M, 1, stream));
+    } else {
+      CHECK(wgrad(bw->d_qkv, 3 * d, h1, d, gl.g_wqkv));
+    }
     CHECK(gpt_gemm_nt(dt, bw->d_qkv, 3 * d, gl.wqkv_t, 3 * d, nullptr, bw->d_h, d, nullptr, 0, M, d, 3 * d, GPT_EPI_STORE, stream));
     CHECK(gpt_layernorm_bwd(bw->d_h, dt, xbuf(2 * l), stat(1 + 2 * l, 0), stat(1 + 2 * l, 1), ly.ln1_w, bw->g, bw->g, bw->gt, dt,
                             gl.g_ln1_w, gl.g_ln1_b, M, d, stream));

@@ -75,6 +75,14 @@ int gpt_gemm_resadd_layernorm(int dtype, const void* A, int64_t lda, const void*
 int gpt_gemm_tn(const void* P, int64_t ldp, const void* Q, int64_t ldq, float* C, int64_t ldc, int I, int J, int R,
                 int accumulate, void* stream);
 
+/* n <= 4 independent gpt_gemm_tn problems with the same contraction length R in ONE launch (arrays of n entries): the
+ * four weight gradients of a Block (query|key|value, proj, mlp.0, mlp.2; the backward of transformer.py:69-72) have too few
+ * 256 x 256 tiles each to fill 256 CUs but fill them together.  No counterpart in the reference (autograd launches one
+ * cuBLAS GEMM per nn.Linear). */
+int gpt_gemm_tn_grouped(int n, const void* const* P, const int64_t* ldp, const void* const* Q, const int64_t* ldq,
+                        float* const* C, const int64_t* ldc, const int* I, const int* J, int R, int accumulate,
+                        void* stream);
+
 /* Measurement aid (bench.py roofline pass; no counterpart in the reference): while enabled, every gpt_gemm_nt
  * launch is bracketed by two HIP events recorded on its own stream (at most 4096 launches per enable);
  * collect waits for them and returns the summed kernel time, the summed algorithmic FLOPs (2 M N K) and the

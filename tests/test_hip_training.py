@@ -307,6 +307,37 @@ def test_gemm_tn_matches_torch(I, J, R, accumulate):
     assert L.lib().gpt_gemm_tn(L.ptr(P), I, L.ptr(Q), J, L.ptr(C), J, I, J, R - 32, 0, L.stream()) != 0
 
 
+@pytest.mark.parametrize("R", [832, 3328])
+def test_gemm_tn_grouped_matches_single_launches(R):
+    """The four weight gradients of a Block in one launch (gpt_gemm_tn_grouped) against fp64 products: different shapes per
+    problem, accumulation into existing values, one shared contraction length."""
+    import ctypes as C
+    d = 256
+    shapes = [(d, 4 * d), (4 * d, d), (3 * d, d), (d, d)]            # (I, J) of mlp.2, mlp.0, qkv, proj
+    g = torch.Generator().manual_seed(R)
+    Ps = [torch.randn(R, i, generator=g).bfloat16().to(DEV) for i, _ in shapes]
+    Qs = [torch.randn(R, j, generator=g).bfloat16().to(DEV) for _, j in shapes]
+    C0 = [torch.randn(i, j, generator=g).to(DEV) for i, j in shapes]
+    Cs = [c.clone() for c in C0]
+    n = len(shapes)
+    vp, i64, i32 = C.c_void_p * n, C.c_int64 * n, C.c_int * n
+    rc = L.lib().gpt_gemm_tn_grouped(n, vp(*[p.data_ptr() for p in Ps]), i64(*[i for i, _ in shapes]),
+                                     vp(*[q.data_ptr() for q in Qs]), i64(*[j for _, j in shapes]),
+                                     vp(*[c.data_ptr() for c in Cs]), i64(*[j for _, j in shapes]),
+                                     i32(*[i for i, _ in shapes]), i32(*[j for _, j in shapes]), R, 1, L.stream())
+    L.check(rc, "gpt_gemm_tn_grouped")
+    torch.cuda.synchronize()
+    for P, Q, c0, c in zip(Ps, Qs, C0, Cs):
+        ref = P.double().t() @ Q.double() + c0.double()
+        assert float((c.double() - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+    # more than 4 problems, or a ragged shape in any of them: rejected before launch
+    assert L.lib().gpt_gemm_tn_grouped(5, vp(), i64(), vp(), i64(), vp(), i64(), i32(), i32(), R, 1, L.stream()) != 0
+    assert L.lib().gpt_gemm_tn_grouped(n, vp(*[p.data_ptr() for p in Ps]), i64(*[i for i, _ in shapes]),
+                                       vp(*[q.data_ptr() for q in Qs]), i64(*[j for _, j in shapes]),
+                                       vp(*[c.data_ptr() for c in Cs]), i64(*[j for _, j in shapes]),
+                                       i32(d, 4 * d, 3 * d, d + 8), i32(*[j for _, j in shapes]), R, 1, L.stream()) != 0
+
+
 def test_wgrad_tn_path_equals_transpose_path():
     """The weight gradients through the TN kernel (cifar_small: d = 256, B*T % 64 == 0) equal the transpose + NT route."""
     import os

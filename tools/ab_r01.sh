@@ -1,5 +1,5 @@
 set -e
-run() { echo "== $*"; env "$@" | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d.get('value'))"; }
-B="python bench.py --steps 150 --warmup 20 --no-cpu-baseline --no-train --no-roofline"
-run A=1 timeout -k 10 120 $B --batch 64
-run A=1 timeout -k 10 120 $B
+run() { echo "== $*"; env "$@" | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d.get('value'), d.get('final_loss'))"; }
+run A=1 timeout -k 10 120 python bench.py --mode train --batch 128 --steps 20 --warmup 5 --no-cpu-baseline
+run A=1 timeout -k 10 200 python bench.py --mode train --batch 1024 --steps 10 --warmup 3 --no-cpu-baseline
+run A=1 timeout -k 10 200 python bench.py --mode train --case cifar_big --batch 68 --augment --steps 10 --warmup 3 --no-cpu-baseline
