@@ -4,6 +4,7 @@
 // They implement what autograd derives for Gpt/models/transformer.py:34-51 (attention), :69-72 (Block),
 // :215-242 (encoder / decoder) in the reference; parity is pinned by the gradient fixtures g6_training_*.
 #include "gemm_common.h"
+#include <stdlib.h>
 
 namespace {
 using gemmk::load8;
@@ -42,10 +43,8 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const DyT
                                                             float* __restrict__ gout, OutT* __restrict__ gout_t,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
                                                             int d, int rows_per_block) {
-  extern __shared__ float red[];  // [2][d] per-workgroup partial dgamma / dbeta
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [LNB_WAVES][d]: the waves' partial dgamma, then dbeta
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int c = threadIdx.x; c < 2 * d; c += LNB_WAVES * 64) red[c] = 0.f;
-  __syncthreads();
   f32x4 gam[NCH], pg[NCH], pb[NCH];
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
@@ -98,21 +97,26 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const DyT
       }
     }
   }
+  // workgroup sums of the waves' partials: every wave stores its registers to its own LDS row [wave][d] (plain 16-byte stores),
+  // then each thread adds the 8 rows of its columns and issues the one global atomic per column - first dgamma, then dbeta
+  // through the same buffer.  (LDS float atomics here - 48 ds_add_f32 per lane from 8 waves on the same addresses - were a
+  // 12 us tail of every launch.)
 #pragma unroll
-  for (int ch = 0; ch < NCH; ++ch) {
-    const int c = ch * 256 + lane * 4;
-    if (c < d) {
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass) __syncthreads();
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        atomicAdd(&red[c + j], pg[ch][j]);       // LDS: 4 waves share the workgroup partial
-        atomicAdd(&red[d + c + j], pb[ch][j]);
-      }
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c = ch * 256 + lane * 4;
+      if (c < d) *reinterpret_cast<f32x4*>(red + wave * d + c) = pass ? pb[ch] : pg[ch];
     }
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < d; c += LNB_WAVES * 64) {
-    unsafeAtomicAdd(dgamma + c, red[c]);          // hardware global_atomic_add_f32 (plain atomicAdd is a CAS loop)
-    unsafeAtomicAdd(dbeta + c, red[d + c]);
+    __syncthreads();
+    float* out = pass ? dbeta : dgamma;
+    for (int c = threadIdx.x; c < d; c += LNB_WAVES * 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < LNB_WAVES; ++w) t += red[w * d + c];
+      unsafeAtomicAdd(out + c, t);                 // hardware global_atomic_add_f32 (plain atomicAdd is a CAS loop)
+    }
   }
 }
 
@@ -456,12 +460,23 @@ extern "C" int gpt_layernorm_bwd(const void* dy, int dy_dtype, const float* x, c
   blocks = blocks > 256 ? 256 : blocks;
   const int rpb = (rows + blocks - 1) / blocks;
   const dim3 grid((rows + rpb - 1) / rpb), block(LNB_WAVES * 64);
-  const size_t lds = 2 * (size_t)d * sizeof(float);
+  const size_t lds = (size_t)LNB_WAVES * d * sizeof(float);   // <= 96 KiB at d = 3072
   hipStream_t s = (hipStream_t)stream;
   const bool dyb = dy_dtype == GPT_BF16, ob = gout_t_dtype == GPT_BF16;
 #define LNB(DY, OUT, NCH)                                                                                              \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<DY, OUT, NCH>), grid, block, lds, s, (const DY*)dy, x, mean, rstd, gamma, resid, \
-                     gout, (OUT*)gout_t, dgamma, dbeta, rows, d, rpb)
+  do {                                                                                                                  \
+    static bool attr_set = false; /* more than 64 KiB of dynamic LDS (d > 2048) must be granted once per kernel */      \
+    if (!attr_set) {                                                                                                    \
+      if (hipFuncSetAttribute((const void*)layernorm_bwd_kernel<DY, OUT, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              LNB_WAVES * NCH * 256 * (int)sizeof(float)) != hipSuccess) {                              \
+        gpt_set_error("gpt_layernorm_bwd: cannot reserve LDS");                                                         \
+        return -1;                                                                                                      \
+      }                                                                                                                 \
+      attr_set = true;                                                                                                  \
+    }                                                                                                                   \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<DY, OUT, NCH>), grid, block, lds, s, (const DY*)dy, x, mean, rstd, gamma, resid, \
+                       gout, (OUT*)gout_t, dgamma, dbeta, rows, d, rpb);                                                \
+  } while (0)
 #define LNB_T(NCH)                         \
   do {                                     \
     if (dyb && ob) LNB(bf16_t, bf16_t, NCH); \

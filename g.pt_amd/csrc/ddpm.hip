@@ -263,6 +263,34 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ sr
   }
 }
 
+// bf16, 16-byte global accesses on both sides (the kernel above moves 2 bytes per lane and instruction: 1.7 TB/s on the weight
+// transposes of the training step): a 64 x 64 tile is scattered TRANSPOSED into LDS (pitch 66 elements: the 8 x 8 (chunk, row)
+// lanes of a wave hit distinct banks), then read back as rows of the output.  Needs cols % 8 == 0, ld_dst % 8 == 0.
+__global__ __launch_bounds__(256) void transpose16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int rows, int cols,
+                                                          int64_t ld_dst) {
+  constexpr int PT = 66;
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64 * PT];     // tile[c][r]
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  const int q = threadIdx.x & 7, row8 = threadIdx.x >> 3;          // 8 chunks of 8 elements x 32 rows per pass
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = row8 + 32 * i, c = c0 + 8 * q;
+    u32x4 v = u32x4{0, 0, 0, 0};
+    if (r0 + r < rows && c < cols) v = *reinterpret_cast<const u32x4*>(src + (int64_t)(r0 + r) * cols + c);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tile[(8 * q + k) * PT + r] = (bf16_t)(v[k >> 1] >> (16 * (k & 1)));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = row8 + 32 * i, r = r0 + 8 * q;
+    if (c0 + c < cols && r < ld_dst) {
+      const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile + c * PT + 8 * q);   // (c * 66 + 8 q) * 2 bytes: 4-byte aligned
+      *reinterpret_cast<u32x4*>(dst + (int64_t)(c0 + c) * ld_dst + r) = u32x4{t32[0], t32[1], t32[2], t32[3]};
+    }
+  }
+}
+
 inline int blocks_for(int64_t n) {
   int64_t b = (n + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -403,7 +431,9 @@ extern "C" int gpt_transpose(int dtype, const void* src, void* dst, int rows, in
   GPT_REQUIRE(dtype == GPT_F32 || dtype == GPT_BF16, "gpt_transpose: bad dtype %d", dtype);
   GPT_REQUIRE(src && dst && rows > 0 && cols > 0 && ld_dst >= rows, "gpt_transpose: bad arguments");
   const dim3 grid((cols + 63) / 64, (int)((ld_dst + 63) / 64));
-  if (dtype == GPT_BF16)
+  if (dtype == GPT_BF16 && cols % 8 == 0 && ld_dst % 8 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0)
+    hipLaunchKernelGGL(transpose16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, rows, cols, ld_dst);
+  else if (dtype == GPT_BF16)
     hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, rows, cols, ld_dst);
   else
     hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, (float*)dst, rows, cols, ld_dst);

@@ -35,7 +35,7 @@ def test_attention_backward(dtype, tol, H, hd, T):
     assert rel_err(dqkv.float().cpu(), qkv.grad) < tol
 
 
-@pytest.mark.parametrize("d", [192, 1536])
+@pytest.mark.parametrize("d", [192, 1536, 2048, 3072, 520])      # 3072: 96 KiB of LDS for the workgroup reduction
 @pytest.mark.parametrize("dy_dtype", ["fp32", "bf16"])
 def test_layernorm_backward(d, dy_dtype):
     g = torch.Generator().manual_seed(d)
@@ -76,6 +76,14 @@ def test_small_gemm_colsum_transpose():
     Xt = torch.full((500, 320), 7.0, device=DEV)
     L.check(L.lib().gpt_transpose(L.F32, L.ptr(X), L.ptr(Xt), 300, 500, 320, L.stream()), "transpose")
     assert torch.equal(Xt[:, :300].cpu(), X.cpu().t()) and float(Xt[:, 300:].abs().max()) == 0
+    # bf16: the 16-byte path (cols % 8 == 0, ld_dst % 8 == 0) with ragged tile counts and zero-filled padding, and the
+    # 2-byte path for the other shapes
+    for rows, cols, ld in ((300, 504, 320), (1536, 6144, 1536), (70, 64, 72), (300, 500, 320), (64, 72, 70)):
+        Xb = torch.randn(rows, cols, generator=g).to(DEV).bfloat16()
+        Xbt = torch.full((cols, ld), 7.0, device=DEV, dtype=torch.bfloat16)
+        L.check(L.lib().gpt_transpose(L.BF16, L.ptr(Xb), L.ptr(Xbt), rows, cols, ld, L.stream()), "transpose")
+        assert torch.equal(Xbt[:, :rows].cpu(), Xb.cpu().t())
+        assert ld == rows or float(Xbt[:, rows:].float().abs().max()) == 0
 
 
 @pytest.mark.parametrize("case,tag", [("mnist_small", "x0"), ("mnist_small", "eps"), ("cifar_small", "x0")])
