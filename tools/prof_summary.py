@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 kernel_stats.csv: per-step time of the top kernels.  usage: prof_summary.py <dir> <steps>"""
-import csv, glob, sys
-f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True))[-1]
+import csv, glob, os, sys
+f = max(glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
 steps = float(sys.argv[2])
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 22
 rows = list(csv.DictReader(open(f)))
