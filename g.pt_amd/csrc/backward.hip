@@ -274,52 +274,98 @@ __device__ __forceinline__ f32x16 rows_product(const T* __restrict__ a_rows, con
 }
 
 // out^T[dd][col] = scale * sum_row src[row][dd] * X[row][col]   (X = accumulator tile, contraction over its rows);
-// written to dst[col][dd] (row-major [T][ld_out] slice of one head)
+// written to dst[col][dd] (row-major [T][ld_out] slice of one head).
+// bf16: as in attention.hip, the src tile [T x HD] is staged into the wave's LDS tile `lt` by coalesced 16-byte loads (rows >= T
+// zero) and its transposed fragments (8 rows of one head-dim per lane) come from ds_read_b64_tr_b16 - the scalar form took 48
+// two-byte global loads per lane and call; the result goes back through the same tile and leaves as 16-byte stores that cover
+// whole rows of the head.  Only the wave itself touches its tile.
+typedef short bwd_v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bwd_v4s* bwd_lds_v4s_ptr;
+template <int HD>
+constexpr int bwd_v_pitch = HD == 128 ? 320 : 192;   // conflict-free pitches of the transposing read (attention.hip)
+template <int HD>
+constexpr int bwd_tile_bytes = 32 * ((HD * 2 + 16) > bwd_v_pitch<HD> ? (HD * 2 + 16) : bwd_v_pitch<HD>);
+
 template <typename T, int HD>
 __device__ __forceinline__ void cols_product_store(const T* __restrict__ src, int64_t ld, const f32x16& X, float scale,
-                                                   T* __restrict__ dst, int64_t ld_out, int r, int hh, int Ttok) {
+                                                   T* __restrict__ dst, int64_t ld_out, int r, int hh, int Ttok, char* lt) {
   constexpr int ND = HD / 32;
-  bf16x8 xp[2];
   if constexpr (sizeof(T) == 2) {
+    constexpr int VP = bwd_v_pitch<HD>, OP = HD * 2 + 16, CPR = HD / 8, NVL = (32 * CPR + 63) / 64;
+    const int lane = r + 32 * hh;
+    bf16x8 xp[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) xp[s][j] = (short)f32_to_bf16(X[8 * s + j]);
-  }
+      for (int j = 0; j < 8; j += 2) {
+        const uint32_t pk = pack_bf16x2(X[8 * s + j], X[8 * s + j + 1]);
+        xp[s][j] = (short)(pk & 0xffffu);
+        xp[s][j + 1] = (short)(pk >> 16);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous use of the tile (its output reads) is over
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int t = 0; t < ND; ++t) {
-    f32x16 O;
+    for (int i = 0; i < NVL; ++i) {
+      const int c = lane + 64 * i, row = c / CPR, col = c - row * CPR;
+      u32x4 v = u32x4{0, 0, 0, 0};
+      if (row < Ttok) v = *reinterpret_cast<const u32x4*>(src + (int64_t)row * ld + col * 8);
+      if (c < 32 * CPR) *reinterpret_cast<u32x4*>(lt + row * VP + col * 16) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own writes only: the LDS serves one wave's instructions in order
+    __builtin_amdgcn_wave_barrier();
+    const int gq = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+    const char* tbase = lt + (4 * (gq >> 1) + tq) * VP + (16 * (gq & 1) + 4 * tp) * 2;
+    f32x16 O[ND];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) O[e] = 0.f;
-    if constexpr (sizeof(T) == 2) {
+    for (int t = 0; t < ND; ++t) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) O[t][e] = 0.f;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        bf16x8 v;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int row = row_of(8 * s + j, hh);
-          v[j] = row < Ttok ? (short)src[(int64_t)row * ld + t * 32 + r] : (short)0;
-        }
-        O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v, xp[s], O, 0, 0, 0);
+        const bwd_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bwd_lds_v4s_ptr)(tbase + (16 * s) * VP + t * 64));
+        const bwd_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bwd_lds_v4s_ptr)(tbase + (16 * s + 8) * VP + t * 64));
+        const bf16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v, xp[s], O[t], 0, 0, 0);
       }
-    } else {
+    }
+    // output tile through LDS: pitch HD * 2 + 16 (see attention.hip), then 16-byte row stores
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (r < Ttok) {
+#pragma unroll
+      for (int t = 0; t < ND; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 o;
+          o.x = pack_bf16x2(O[t][4 * g] * scale, O[t][4 * g + 1] * scale);
+          o.y = pack_bf16x2(O[t][4 * g + 2] * scale, O[t][4 * g + 3] * scale);
+          *reinterpret_cast<uint2*>(lt + r * OP + (t * 32 + 8 * g + 4 * hh) * 2) = o;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const int nchunk = Ttok * CPR;
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+      const int c = lane + 64 * i, row = c / CPR, col = c - row * CPR;
+      if (c < nchunk) *reinterpret_cast<u32x4*>(dst + (int64_t)row * ld_out + col * 8) = *reinterpret_cast<const u32x4*>(lt + row * OP + col * 16);
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < ND; ++t) {
+      f32x16 O;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) O[e] = 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = row_of(e, hh);
         const float v = row < Ttok ? src[(int64_t)row * ld + t * 32 + r] : 0.f;
         O = __builtin_amdgcn_mfma_f32_32x32x2f32(v, X[e], O, 0, 0, 0);
       }
-    }
-    if (r < Ttok) {
+      if (r < Ttok) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        T* p = dst + (int64_t)r * ld_out + t * 32 + 8 * g + 4 * hh;
-        if constexpr (sizeof(T) == 2) {
-          uint2 o;
-          o.x = pack_bf16x2(O[4 * g] * scale, O[4 * g + 1] * scale);
-          o.y = pack_bf16x2(O[4 * g + 2] * scale, O[4 * g + 3] * scale);
-          *reinterpret_cast<uint2*>(p) = o;
-        } else {
+        for (int g = 0; g < 4; ++g) {
+          T* p = dst + (int64_t)r * ld_out + t * 32 + 8 * g + 4 * hh;
           *reinterpret_cast<float4*>(p) = make_float4(O[4 * g] * scale, O[4 * g + 1] * scale, O[4 * g + 2] * scale, O[4 * g + 3] * scale);
         }
       }
@@ -346,6 +392,8 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict_
   T* dvb = dqb + 2 * d;
   const bool valid = r < Ttok;
   const float scale = 1.0f / sqrtf((float)HD);
+  __shared__ __attribute__((aligned(16))) char lds_tiles[sizeof(T) == 2 ? 4 * bwd_tile_bytes<HD> : 16];
+  char* lt = lds_tiles + (sizeof(T) == 2 ? (threadIdx.x >> 6) * bwd_tile_bytes<HD> : 0);
 
   // keys on rows, query r on this lane
   f32x16 St = rows_product<T, HD>(kb, qb, ld, r, hh, valid);
@@ -403,7 +451,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict_
 #pragma unroll
   for (int e = 0; e < 16; ++e) dSt[e] = St[e] * (dPt[e] - delta);
   // dQ[query][dd] = scale * sum_key dS[query][key] K[key][dd]
-  cols_product_store<T, HD>(kb, ld, dSt, scale, dqb, ld, r, hh, Ttok);
+  cols_product_store<T, HD>(kb, ld, dSt, scale, dqb, ld, r, hh, Ttok, lt);
 
   // queries on rows, key r on this lane: P[query][key] = exp(scale * S - lse_query)
   f32x16 S = rows_product<T, HD>(qb, kb, ld, r, hh, valid);
@@ -444,8 +492,8 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict_
     dS[e] = P[e] * (dP[e] - delta_q);
   }
   // dK[key][dd] = scale * sum_query dS[query][key] Q[query][dd];   dV[key][dd] = sum_query P[query][key] dO[query][dd]
-  cols_product_store<T, HD>(qb, ld, dS, scale, dkb, ld, r, hh, Ttok);
-  cols_product_store<T, HD>(dob, d, P, 1.0f, dvb, ld, r, hh, Ttok);
+  cols_product_store<T, HD>(qb, ld, dS, scale, dkb, ld, r, hh, Ttok, lt);
+  cols_product_store<T, HD>(dob, d, P, 1.0f, dvb, ld, r, hh, Ttok, lt);
 }
 
 }  // namespace
