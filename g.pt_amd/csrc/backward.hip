@@ -160,30 +160,76 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, in
 // C[m, n] (+)= sum_k A(m, k) * B(k, n), exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), arbitrary element strides: the
 // ragged encoder / decoder gradients (0.4 % of the FLOPs; K = batch or a token width).  64 x 64 tile per workgroup
 // (one 32 x 32 accumulator per wave), 32-deep chunks staged through LDS so either operand may be K- or M/N-major.
+// One operand's [KC x 64] chunk into LDS when its M / N index is the contiguous one (the gradients whose contraction runs over
+// the batch): 16-byte loads along the row instead of one element per lane and iteration - the element-wise staging, not the
+// MFMAs, was what these launches spent their time on.  vec_ok: base and row stride are 16-byte aligned (else per element).
+constexpr int SG_KC = 32, SG_PITCH = 68;   // 68 floats: 16-byte aligned rows, conflict-free 32-lane reads
+template <typename T>
+__device__ __forceinline__ void sg_stage_contig(float (*S)[SG_PITCH], const T* __restrict__ base, int64_t sk, int i0, int I, int k0,
+                                                int K, bool vec_ok) {
+  constexpr int VE = 16 / sizeof(T), VPR = 64 / VE;     // elements per 16 bytes, vectors per 64-wide row
+  for (int i = threadIdx.x; i < SG_KC * VPR; i += 256) {
+    const int kk = i / VPR, iv = (i % VPR) * VE;
+    const int k = k0 + kk, idx = i0 + iv;
+    float vals[VE];
+    const T* p = base + (int64_t)k * sk + idx;
+    if (k < K && idx + VE <= I && vec_ok) {
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(p);
+      if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vals[e] = __uint_as_float(raw[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          vals[2 * e] = __uint_as_float(raw[e] << 16);
+          vals[2 * e + 1] = __uint_as_float(raw[e] & 0xffff0000u);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) vals[e] = (k < K && idx + e < I) ? elem<T>::load(p + e) : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < VE; e += 4) *reinterpret_cast<f32x4*>(&S[kk][iv + e]) = f32x4{vals[e], vals[e + 1], vals[e + 2], vals[e + 3]};
+  }
+}
+
 template <typename TA, typename TB>
 __device__ __forceinline__ void small_gemm_tile(const TA* __restrict__ A, int64_t a_sm, int64_t a_sk,
                                                 const TB* __restrict__ B, int64_t b_sk, int64_t b_sn,
                                                 float* __restrict__ C, int64_t ldc, int M, int N, int K,
                                                 int accumulate) {
-  constexpr int KC = 32;
-  __shared__ float As[KC][65], Bs[KC][65];
+  constexpr int KC = SG_KC;
+  __shared__ __attribute__((aligned(16))) float As[KC][SG_PITCH], Bs[KC][SG_PITCH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const bool a_vec = a_sm == 1 && ((uintptr_t)A % 16) == 0 && (a_sk * (int64_t)sizeof(TA)) % 16 == 0;
+  const bool b_vec = b_sn == 1 && ((uintptr_t)B % 16) == 0 && (b_sk * (int64_t)sizeof(TB)) % 16 == 0;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   for (int k0 = 0; k0 < K; k0 += KC) {
-    for (int i = threadIdx.x; i < KC * 64; i += 256) {
-      // lay the loads out along whichever index is contiguous in memory
-      int kk, mm;
-      if (a_sk == 1) { kk = i & (KC - 1); mm = i / KC; } else { mm = i & 63; kk = i >> 6; }
-      const int m = m0 + mm, k = k0 + kk;
-      As[kk][mm] = (m < M && k < K) ? elem<TA>::load(A + m * a_sm + k * a_sk) : 0.f;
-      int kb, nn;
-      if (b_sk == 1) { kb = i & (KC - 1); nn = i / KC; } else { nn = i & 63; kb = i >> 6; }
-      const int n = n0 + nn, k2 = k0 + kb;
-      Bs[kb][nn] = (n < N && k2 < K) ? elem<TB>::load(B + k2 * b_sk + n * b_sn) : 0.f;
+    if (a_sm == 1) {
+      sg_stage_contig<TA>(As, A, a_sk, m0, M, k0, K, a_vec);
+    } else {
+      for (int i = threadIdx.x; i < KC * 64; i += 256) {
+        // lay the loads out along whichever index is contiguous in memory
+        int kk, mm;
+        if (a_sk == 1) { kk = i & (KC - 1); mm = i / KC; } else { mm = i & 63; kk = i >> 6; }
+        const int m = m0 + mm, k = k0 + kk;
+        As[kk][mm] = (m < M && k < K) ? elem<TA>::load(A + m * a_sm + k * a_sk) : 0.f;
+      }
+    }
+    if (b_sn == 1) {
+      sg_stage_contig<TB>(Bs, B, b_sk, n0, N, k0, K, b_vec);
+    } else {
+      for (int i = threadIdx.x; i < KC * 64; i += 256) {
+        int kb, nn;
+        if (b_sk == 1) { kb = i & (KC - 1); nn = i / KC; } else { nn = i & 63; kb = i >> 6; }
+        const int n = n0 + nn, k2 = k0 + kb;
+        Bs[kb][nn] = (n < N && k2 < K) ? elem<TB>::load(B + k2 * b_sk + n * b_sn) : 0.f;
+      }
     }
     __syncthreads();
 #pragma unroll
