@@ -102,10 +102,14 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_ema_kernel(OptArgs a) {
     const float coef = a.clip / (norm + 1e-6f);
     scale = scale * fminf(coef, 1.0f);
   }
-  f32x4 p = reinterpret_cast<f32x4*>(a.p)[i4];
-  f32x4 g = reinterpret_cast<f32x4*>(a.g)[i4];
-  f32x4 m = reinterpret_cast<f32x4*>(a.m)[i4];
-  f32x4 v = reinterpret_cast<f32x4*>(a.v)[i4];
+  // all five streams are read before anything is written (the arena pointers may alias as far as the compiler knows, so a
+  // load placed after a store waits for it), and every access is non-temporal: 1.5 GB per stream, nothing is re-used
+  f32x4 p = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.p) + i4);
+  f32x4 g = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.g) + i4);
+  f32x4 m = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.m) + i4);
+  f32x4 v = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.v) + i4);
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (a.ema) s = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(a.ema) + i4);
   const float decay = sg.decay ? a.decay_mul : 1.0f;
   const float w1 = a.w1, w2 = a.w2;
 #pragma unroll
@@ -120,16 +124,15 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_ema_kernel(OptArgs a) {
     m[j] = mj;
     v[j] = vj;
   }
-  reinterpret_cast<f32x4*>(a.p)[i4] = p;
-  reinterpret_cast<f32x4*>(a.m)[i4] = m;
-  reinterpret_cast<f32x4*>(a.v)[i4] = v;
-  if (a.zero_grad) reinterpret_cast<f32x4*>(a.g)[i4] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __builtin_nontemporal_store(p, reinterpret_cast<f32x4*>(a.p) + i4);
+  __builtin_nontemporal_store(m, reinterpret_cast<f32x4*>(a.m) + i4);
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.v) + i4);
+  if (a.zero_grad) __builtin_nontemporal_store(f32x4{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f32x4*>(a.g) + i4);
   if (a.ema) {
-    f32x4 s = reinterpret_cast<f32x4*>(a.ema)[i4];
     const float alpha = a.ema_alpha;
 #pragma unroll
     for (int j = 0; j < 4; ++j) s[j] = s[j] * a.ema_decay + p[j] * alpha;
-    reinterpret_cast<f32x4*>(a.ema)[i4] = s;
+    __builtin_nontemporal_store(s, reinterpret_cast<f32x4*>(a.ema) + i4);
   }
   if (a.packed && sg.packed_off >= 0) write_packed(a.packed, a.packed_dtype, sg, e, p);
 }
