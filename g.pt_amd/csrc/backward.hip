@@ -132,7 +132,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, in
   const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (vec && c0 + 8 <= cols) {
-    for (int r = r0 + rl; r < r1; r += 8) {
+    // four rows' loads in flight per thread (one per iteration kept a CU's bytes in flight too few for the HBM latency)
+    int r = r0 + rl;
+    for (; r + 24 < r1; r += 32) {
+      float4 a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) load8<T>(X + (int64_t)(r + 8 * u) * ld + c0, a[u], b[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s[0] += a[u].x; s[1] += a[u].y; s[2] += a[u].z; s[3] += a[u].w;
+        s[4] += b[u].x; s[5] += b[u].y; s[6] += b[u].z; s[7] += b[u].w;
+      }
+    }
+    for (; r < r1; r += 8) {
       float4 a, b;
       load8<T>(X + (int64_t)r * ld + c0, a, b);
       s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
