@@ -156,7 +156,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or os.environ.get("GPT_DP_REHEARSE") == "1":   # one-rank rehearsal of the RCCL calls: g.pt_amd/dp.py exchanging()
         dist.init_process_group("nccl", device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
@@ -169,7 +169,7 @@ def main():
             line["train"] = guarded_train(args, device, world, rank, line)
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dp.exchanging():
         dist.barrier()
         dist.destroy_process_group()
 
@@ -231,7 +231,7 @@ def pmc_mfma_util(case, B, dtype):
 
 
 def sync_all(world):
-    if world > 1:
+    if dp.exchanging():
         dist.barrier()
     torch.cuda.synchronize()
 
@@ -248,11 +248,11 @@ def bench_sample(args, device, world, rank):
     t0 = time.perf_counter()
     runner.run(args.steps)
     local_rows = runner.x
-    if world > 1:                                             # the only traffic: final gather of the samples
+    if dp.exchanging():                                       # the only traffic: final gather of the samples
         local_rows = dp.gather_rows(runner.x, B * world)
     sync_all(world)
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dp.exchanging():
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())

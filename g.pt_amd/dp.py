@@ -3,12 +3,21 @@
 exchange used by the training step (reference: DistributedDataParallel, main.py:229-240).
 
 One process per GPU; single-process calls short-circuit exactly as the reference's do."""
+import os
+
 import torch
 import torch.distributed as dist
 
 
 def _live():
     return dist.is_available() and dist.is_initialized()
+
+
+def exchanging():
+    """True when the collectives must run: more than one rank, or a one-rank process group under GPT_DP_REHEARSE=1
+    (the RCCL calls of the multi-GPU path rehearsed on a one-GPU box: a one-rank SUM / gather / broadcast is the
+    identity, so results must equal the single-process path's; tests/test_hip_training.py::test_one_rank_rccl_rehearsal_matches_single_process)."""
+    return _live() and (dist.get_world_size() > 1 or os.environ.get("GPT_DP_REHEARSE") == "1")
 
 
 def is_main_proc(local=False):
@@ -24,7 +33,7 @@ def get_world_size():
 
 
 def synchronize():
-    if get_world_size() > 1:
+    if exchanging():
         dist.barrier()
 
 
@@ -50,7 +59,7 @@ def scaled_all_reduce(cfg, tensors):
 
 def all_gather(input, cat=True, dim=0):
     """distributed.py:170-183."""
-    if get_world_size() == 1:
+    if not exchanging():
         return input if cat else input.unsqueeze(dim)
     parts = [torch.empty_like(input) for _ in range(get_world_size())]
     dist.all_gather(parts, input.contiguous())
@@ -59,7 +68,7 @@ def all_gather(input, cat=True, dim=0):
 
 def rank0_to_all(input, cat=True):
     """Rank 0's value on every rank (distributed.py:186-189) as a broadcast."""
-    if get_world_size() == 1:
+    if not exchanging():
         return (input if cat else input.unsqueeze(0))[0]
     out = input.clone()
     dist.broadcast(out, src=0)
@@ -78,7 +87,7 @@ def shard_rows(n_rows, rank=None, world=None):
 def gather_rows(local, n_rows):
     """Final gather of row-sharded samples: (B_local, D) per rank -> (n_rows, D) on every rank."""
     world = get_world_size()
-    if world == 1:
+    if not exchanging():
         return local
     per = (n_rows + world - 1) // world
     pad = torch.zeros(per, *local.shape[1:], dtype=local.dtype, device=local.device)
@@ -91,7 +100,7 @@ def gather_rows(local, n_rows):
 def broadcast_parameters(module, src=0):
     """Initial parameter broadcast from rank 0 (what DDP does at construction, main.py:231-236), coalesced into one
     message per dtype instead of one collective per tensor."""
-    if get_world_size() == 1:
+    if not exchanging():
         return
     by_dtype = {}
     for t in list(module.parameters()) + list(module.buffers()):
@@ -162,7 +171,7 @@ def all_reduce_ranges(flat, ranges, async_op=True):
     The 1/world scale is NOT applied (the fused optimizer pass folds it in).
     A process group without a device transport (gloo: the CPU rehearsal of the multi-GPU path) gets device buffers
     staged through the host, synchronously."""
-    if get_world_size() == 1:
+    if not exchanging():
         return []
     if flat.is_cuda and dist.get_backend() != "nccl":
         for lo, hi in ranges:

@@ -61,7 +61,7 @@ class TrainStep:
         self._side, self._t_ready = None, None
         self.world = dp.get_world_size()
         self.flat = FlatState(model, self.device)
-        if self.world > 1:                              # rank 0's weights everywhere (DDP construction, main.py:231-236)
+        if dp.exchanging():                             # rank 0's weights everywhere (DDP construction, main.py:231-236)
             dist.broadcast(self.flat.params, src=0)
         self.ema = None
         if use_ema:
@@ -135,7 +135,7 @@ class TrainStep:
         # soon as the backward stages that fill it are enqueued, and overlaps with the remaining stages
         self._handles = []
         schedule = None
-        if self.world > 1 and self.overlap:
+        if dp.exchanging() and self.overlap:
             schedule = [(stage_end, (lambda lo=lo, hi=hi: self._handles.extend(dp.all_reduce_ranges(self.grads, [(lo, hi)]))))
                         for lo, hi, stage_end in self.buckets]
         if self._t_ready is not None:
@@ -148,7 +148,7 @@ class TrainStep:
     def exchange(self):
         """Completes the gradient exchange (launches it here when not overlapped); the 1/world scale is folded into the
         optimizer pass."""
-        if self.world > 1 and not self.overlap:
+        if dp.exchanging() and not self.overlap:
             self._handles = dp.all_reduce_ranges(self.grads, [(lo, hi) for lo, hi, _ in self.buckets])
         dp.wait_all(self._handles)
         self._handles = []
@@ -288,7 +288,7 @@ def bench_train(args, device, world, rank):
     mse = run(args.steps, args.warmup)
     sync_all(world)
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dp.exchanging():
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())

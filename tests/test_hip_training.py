@@ -299,6 +299,68 @@ def test_two_rank_step_equals_full_batch(tmp_path):
         assert float((p.detach().cpu() - got[k]).abs().max()) < 5e-5 * max(1.0, float(got[k].abs().max())), k
 
 
+def _rccl_rank(port, out_path):
+    """The multi-GPU code path on RCCL with the one rank a one-GPU box allows (GPT_DP_REHEARSE=1, dp.exchanging()):
+    parameter broadcast, bucketed asynchronous gradient all-reduces on RCCL's stream overlapped with the backward stages,
+    the final row gather and the helper collectives all really run; with one rank each is the identity."""
+    import faulthandler
+    import os
+    import torch.distributed as dist
+    faulthandler.dump_traceback_later(100, exit=True)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", GPT_DP_REHEARSE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from gpt_amd import dp
+        from gpt_amd.trainstep import TrainStep
+        assert dp.exchanging() and dp.get_world_size() == 1
+        m, plan, sd = build("mnist_small", "fp32", seed=3)
+        m.train()
+        dp.broadcast_parameters(m)
+        diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
+        ts = TrainStep(m, diff, lr=1e-3, wd=0.1, grad_clip=0.75, bucket_layers=1)
+        for i in range(2):
+            ts.step(*_ddp_batch(i))
+        rows = torch.arange(5 * 7, dtype=torch.float32, device=DEV).view(5, 7)
+        assert torch.equal(dp.gather_rows(rows, 5), rows)
+        assert torch.equal(dp.all_gather(rows), rows) and dp.all_gather(rows, cat=False).shape == (1, 5, 7)
+        assert torch.equal(dp.rank0_to_all(rows), rows[0])
+        dp.synchronize()
+        torch.cuda.synchronize()
+        torch.save({k: p.detach().cpu() for k, p in m.named_parameters()}, out_path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_rccl_rehearsal_matches_single_process(tmp_path):
+    """The RCCL calls of the data-parallel step (never reachable with one rank otherwise) against the single-process step."""
+    import socket
+    import torch.multiprocessing as mp
+    from gpt_amd.trainstep import TrainStep
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out_path = str(tmp_path / "rccl.pt")
+    p = mp.get_context("spawn").Process(target=_rccl_rank, args=(port, out_path))
+    p.start()
+    p.join(timeout=150)
+    if p.exitcode is None:
+        p.kill()
+    assert p.exitcode == 0
+    got = torch.load(out_path, weights_only=True)
+    m, plan, sd = build("mnist_small", "fp32", seed=3)
+    m.train()
+    diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
+    ts = TrainStep(m, diff, lr=1e-3, wd=0.1, grad_clip=0.75)
+    for i in range(2):
+        ts.step(*_ddp_batch(i))
+    for k, prm in m.named_parameters():
+        if k.endswith("attn.key.bias"):
+            continue
+        assert float((prm.detach().cpu() - got[k]).abs().max()) < 5e-5 * max(1.0, float(got[k].abs().max())), k
+
+
 @pytest.mark.parametrize("I,J,R", [(256, 256, 64), (512, 768, 832), (1536, 256, 3328), (256, 512, 8256)])   # last: 16 row spans, ragged
 @pytest.mark.parametrize("accumulate", [0, 1])
 def test_gemm_tn_matches_torch(I, J, R, accumulate):
