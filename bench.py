@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 import gpt_amd                                   # noqa: E402
 from gpt_amd import _lib as L                    # noqa: E402
 from gpt_amd import dp                           # noqa: E402
-from tests.cases import CASES, gpt_kwargs        # noqa: E402
+from gpt_amd.configs import CASES, gpt_kwargs    # noqa: E402
 
 PEAK = {"bf16": 2500.0, "fp32": 157.3}          # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
 

@@ -208,7 +208,7 @@ class TrainStep:
 
 def synthetic_pairs(case, B, device, seed):
     """checkpoint pairs of the MNIST shapes."""
-    from tests.cases import CASES
+    from .configs import CASES
     c = CASES[case]
     D = sum(c["parameter_sizes"])
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -221,7 +221,7 @@ def synthetic_pairs(case, B, device, seed):
 
 
 def c_std(case):
-    from tests.cases import CASES
+    from .configs import CASES
     return CASES[case]["w_std"]
 
 
@@ -229,7 +229,7 @@ def bench_train(args, device, world, rank):
     """bench.py --mode train: configs/train/mnist_loss.yaml hyper-parameters on synthetic checkpoint pairs."""
     import gpt_amd
     from bench import flops_per_forward, make_model, sync_all, PEAK
-    from tests.cases import CASES
+    from .configs import CASES
     case = args.case
     B = args.batch or 128                      # int(1024 / 8): the per-GPU batch of the reference's 8-GPU run
     torch.manual_seed(0)                       # same initial weights on every rank (then broadcast anyway)

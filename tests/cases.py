@@ -4,40 +4,8 @@ the oracle and the HIP path), so that all three see identical inputs.  Input dis
 SURVEY.md section 8(d)."""
 import torch
 
-MNIST_SIZES = [7840, 10, 100, 10]
-MNIST_NAMES = ["fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"]
-CIFAR_SIZES = [432, 4608, 320, 10]
-CIFAR_NAMES = ["conv1.weight", "conv2.weight", "fc.weight", "fc.bias"]
-
-CASES = {
-    # reduced-width models with the real token plans (26 tokens) and the real head dims (96 / 128)
-    "mnist_small": dict(parameter_sizes=MNIST_SIZES, parameter_names=MNIST_NAMES, n_embd=192, n_head=2,
-                        n_layer=2, chunk_size=1000, split_policy="chunk_within_layer", loss_lo=0.3, loss_hi=2.4,
-                        loss_target=0.0, w_std=0.538),
-    "cifar_small": dict(parameter_sizes=CIFAR_SIZES, parameter_names=CIFAR_NAMES, n_embd=256, n_head=2,
-                        n_layer=2, chunk_size=576, split_policy="chunk_within_layer", loss_lo=40.0, loss_hi=90.0,
-                        loss_target=35.0, w_std=0.538),
-    # the pretrained configurations (configs/train/mnist_loss.yaml:34-47, cifar10_error.yaml:34-47)
-    "mnist": dict(parameter_sizes=MNIST_SIZES, parameter_names=MNIST_NAMES, n_embd=1536, n_head=16,
-                  n_layer=12, chunk_size=1000, split_policy="chunk_within_layer", loss_lo=0.3, loss_hi=2.4,
-                  loss_target=0.0, w_std=0.538),
-    "cifar": dict(parameter_sizes=CIFAR_SIZES, parameter_names=CIFAR_NAMES, n_embd=2048, n_head=16,
-                  n_layer=12, chunk_size=576, split_policy="chunk_within_layer", loss_lo=40.0, loss_hi=90.0,
-                  loss_target=35.0, w_std=0.538),
-    # BASELINE.json configs[4]: CIFAR shapes with a scaled-up transformer (the reference defines none; SURVEY.md 8d config 5)
-    "cifar_big": dict(parameter_sizes=CIFAR_SIZES, parameter_names=CIFAR_NAMES, n_embd=3072, n_head=24,
-                      n_layer=24, chunk_size=576, split_policy="chunk_within_layer", loss_lo=40.0, loss_hi=90.0,
-                      loss_target=35.0, w_std=0.538),
-}
-
-
-def gpt_kwargs(case):
-    c = CASES[case]
-    return dict(parameter_sizes=list(c["parameter_sizes"]), parameter_names=list(c["parameter_names"]),
-                num_frequencies=128, max_freq_log2=14, predict_xstart=True, absolute_loss_conditioning=True,
-                n_embd=c["n_embd"], n_head=c["n_head"], n_layer=c["n_layer"], chunk_size=c["chunk_size"],
-                split_policy=c["split_policy"], encoder_depth=1, decoder_depth=1,
-                attn_pdrop=0.0, resid_pdrop=0.0, embd_pdrop=0.0)
+from gpt_amd.configs import (CASES, CIFAR_NAMES, CIFAR_SIZES, MNIST_NAMES, MNIST_SIZES,  # noqa: F401
+                             gpt_kwargs)
 
 
 def make_inputs(case, B, seed):
