@@ -283,7 +283,7 @@ def bench_sample(args, device, world, rank):
         line["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK[args.dtype], "unit": "TFLOP/s",
                             "frac": achieved / PEAK[args.dtype], "traffic": pmc_traffic(case, B, args.dtype),
                             "mfma_util_pmc": pmc_mfma_util(case, B, args.dtype),
-                            "kernel": "gemm256_kernel + gemm_nt_kernel K spans (qkv/proj/fc1/fc2 contractions, 5 GEMM calls per layer)", "launches": nl.value,
+                            "kernel": "gemm256_kernel + gemm_nt_kernel K spans of fc1's row tail (qkv/proj/fc1/fc2 contractions, 5 GEMM calls per layer)", "launches": nl.value,
                             "avg_launch_us": ms.value * 1e3 / max(nl.value, 1),
                             "flops_per_launch": fl.value / max(nl.value, 1)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
