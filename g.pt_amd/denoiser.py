@@ -458,6 +458,8 @@ class Gpt(nn.Module):
         if self.training and self.decoder.dropout_p > 0:
             raise NotImplementedError("dropout > 0 is not implemented on the HIP path (every shipped config uses 0)")
         x, t, lt, lp, x_prev = self._prepare(x, t, loss_target, loss_prev, x_prev)
+        if x.shape[0] == 0:                       # an empty batch: the reference returns an empty (0, D) tensor; no launch
+            return torch.empty_like(x)
         if needs_grad:
             from .autograd import denoise_with_grad
             return denoise_with_grad(self, x, t, lt, lp, x_prev)

@@ -335,6 +335,32 @@ def test_forward_other_split_policies_vs_oracle(sizes, policy, chunk, absolute, 
     assert float((got - ref).abs().max()) / float((ref - xp).abs().max()) < 1e-3
 
 
+@pytest.mark.parametrize("B", [1, 3, 33, 65])
+def test_forward_edge_batches_and_argument_forms(B):
+    """Batches of one row and of row counts no tile divides; the argument forms the reference accepts (transformer.py:440-464,
+    SURVEY.md 8a-5): losses as (B,) or (B, 1), fp32 or fp64, t as int64 or int32; an empty batch returns an empty tensor."""
+    m, plan, sd = build("mnist_small", "fp32", seed=3)
+    cpu = make_inputs("mnist_small", B=B, seed=60 + B)
+    x, t, lt, lp, xp = cpu
+    with torch.no_grad():
+        ref = od.forward(sd, plan, *cpu)
+        scale = float((ref - xp).abs().max())
+        got = m(x.to(DEV), t.to(DEV), lt.to(DEV), loss_prev=lp.to(DEV), x_prev=xp.to(DEV))
+        assert got.shape == (B, plan.D) and float((got.cpu() - ref).abs().max()) / scale < 1e-3
+        alt = m(x.to(DEV), t.int().to(DEV), lt.view(B, 1).to(DEV), loss_prev=lp.view(B, 1).to(DEV), x_prev=xp.to(DEV))
+        assert torch.equal(alt, got)
+        ref64 = od.forward(sd, plan, x, t, lt.double(), lp.double(), xp)
+        got64 = m(x.to(DEV), t.to(DEV), lt.double().to(DEV), loss_prev=lp.double().to(DEV), x_prev=xp.to(DEV))
+        assert float((got64.cpu() - ref64).abs().max()) / scale < 1e-3
+        empty = m(x[:0].to(DEV), t[:0].to(DEV), lt[:0].to(DEV), loss_prev=lp[:0].to(DEV), x_prev=xp[:0].to(DEV))
+        assert empty.shape == (0, plan.D)
+    with pytest.raises(AssertionError):           # shape contracts fail before any launch
+        m(x.to(DEV), t[:-1].to(DEV) if B > 1 else torch.zeros(2, dtype=torch.long, device=DEV), lt.to(DEV), loss_prev=lp.to(DEV),
+          x_prev=xp.to(DEV))
+    with pytest.raises(AssertionError):
+        m(x[:, :-1].to(DEV), t.to(DEV), lt.to(DEV), loss_prev=lp.to(DEV), x_prev=xp[:, :-1].to(DEV))
+
+
 @pytest.mark.parametrize("case", ["mnist_small", "cifar_small"])
 def test_forward_oracle_bf16(case):
     m, plan, sd = build(case, "bf16", seed=3)
