@@ -166,7 +166,10 @@ def main():
     else:
         line = bench_sample(args, device, world, rank)
         if not args.no_train:
-            line["train"] = guarded_train(args, device, world, rank, line)
+            line["train"] = guarded_train(args, device, world, rank, line, "train", max(1, 1024 // world), "strong")
+            # efficiency also at a fixed per-GPU batch: 128 pairs per GPU (the 8-GPU share of 1024) at every N
+            line["train_weak"] = (dict(line["train"], scaling="weak") if 1024 // world == 128 else
+                                  guarded_train(args, device, world, rank, line, "train_weak", 128, "weak"))
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dp.exchanging():
@@ -174,16 +177,17 @@ def main():
         dist.destroy_process_group()
 
 
-def guarded_train(args, device, world, rank, line, limit_s=150.0):
-    """BASELINE.json's second metric (train iters/sec, configs[3]) measured briefly after the headline: global batch
-    1024 = int(1024 / N) pairs per GPU as configs/train/mnist_loss.yaml runs it (strong scaling), 10 timed steps.
+def guarded_train(args, device, world, rank, line, key, batch, scaling, limit_s=150.0):
+    """BASELINE.json's second metric (train iters/sec, configs[3]) measured briefly after the headline, 10 timed steps:
+    "train" at global batch 1024 = int(1024 / N) pairs per GPU as configs/train/mnist_loss.yaml runs it (strong scaling),
+    "train_weak" at 128 pairs per GPU for every N.
     A watchdog prints the headline line without it if the step does not finish (the line must never be lost)."""
     import threading
     from gpt_amd.trainstep import bench_train
 
     def give_up():
         if rank == 0:
-            line["train"] = {"error": f"training step did not finish within {limit_s:.0f} s"}
+            line[key] = {"error": f"training step did not finish within {limit_s:.0f} s"}
             print(json.dumps(line), flush=True)
         os._exit(0)
 
@@ -192,11 +196,11 @@ def guarded_train(args, device, world, rank, line, limit_s=150.0):
     timer.start()
     try:
         targs = argparse.Namespace(**vars(args))
-        targs.steps, targs.warmup, targs.batch = 10, 3, max(1, 1024 // world)
+        targs.steps, targs.warmup, targs.batch = 10, 3, batch
         res = bench_train(targs, device, world, rank)
         keep = ("value", "unit", "ms_per_step", "steps", "warmup", "samples_per_s", "model_tflops_per_gpu", "final_loss")
         out = {k: res[k] for k in keep}
-        out.update(metric=res["metric"], scaling="strong", global_batch=res["config"]["global_batch"],
+        out.update(metric=res["metric"], scaling=scaling, global_batch=res["config"]["global_batch"],
                    batch_per_gpu=res["config"]["batch_per_gpu"], workload=res["config"]["workload"])
         return out
     except Exception as e:  # noqa: BLE001 - the headline line must survive a failure of the secondary measurement
