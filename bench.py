@@ -69,8 +69,8 @@ def synth_inputs(case, B, device, seed):
 class SampleRunner:
     """Drives gpt_sample_loop over arbitrary step counts (wrapping around the 1000-step schedule)."""
 
-    def __init__(self, model, diff, B, inputs, device):
-        self.m, self.diff, self.B, self.dev = model, diff, B, device
+    def __init__(self, model, diff, B, inputs, device, seed=1234):
+        self.m, self.diff, self.B, self.dev, self.seed = model, diff, B, device, seed
         self.x, self.lt, self.lp, self.xp = inputs
         self.eng = model.engine(device)
         self.ws = self.eng.workspace(B)
@@ -90,7 +90,7 @@ class SampleRunner:
             first, last = self.cursor, self.cursor - k + 1
             L.check(L.lib().gpt_sample_loop(
                 C.byref(self.eng.cmodel), C.byref(self.ws), L.ptr(self.x), L.ptr(self.lt), L.ptr(self.lp), 0,
-                L.ptr(self.xp), L.ptr(self.coef), self.tmap, n, first, last, 1, 0, 0.0, 0.0, None, 1234,
+                L.ptr(self.xp), L.ptr(self.coef), self.tmap, n, first, last, 1, 0, 0.0, 0.0, None, self.seed,
                 L.ptr(self.t_model), L.ptr(self.t_index), L.ptr(self.model_out), L.ptr(self.noise), self.B,
                 L.stream()), "gpt_sample_loop")
             steps -= k
@@ -244,7 +244,8 @@ def bench_sample(args, device, world, rank):
     case, B = args.case, args.batch or 320
     model = make_model(case, args.dtype, device)
     diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
-    runner = SampleRunner(model, diff, B, synth_inputs(case, B, device, seed=100 + rank), device)
+    runner = SampleRunner(model, diff, B, synth_inputs(case, B, device, seed=100 + rank), device,
+                          seed=1234 * world + rank)      # one Philox stream per rank (Gpt/utils.py:73-75: seed * G + rank)
     D = model.D
 
     runner.run(args.warmup)
