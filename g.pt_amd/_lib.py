@@ -84,6 +84,7 @@ _PROTOS = {
     "gpt_bf16_to_f32": ([vp, vp, i64, vp], i32),
     "gpt_transpose": ([i32, vp, vp, i32, i32, i64, vp], i32),
     "gpt_layernorm_bwd": ([vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp], i32),
+    "gpt_layernorm_bwd_colsum": ([vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp], i32),
     "gpt_attention_bwd": ([i32, vp, vp, vp, i32, i32, i32, i32, vp], i32),
     "gpt_colsum": ([i32, vp, i64, vp, i32, i32, vp], i32),
     "gpt_small_gemm": ([i32, vp, i64, i64, i32, vp, i64, i64, vp, i64, i32, i32, i32, i32, vp], i32),

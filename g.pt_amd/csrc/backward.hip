@@ -41,16 +41,18 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const DyT
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ resid,
                                                             float* __restrict__ gout, OutT* __restrict__ gout_t,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
-                                                            int d, int rows_per_block) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [LNB_WAVES][d]: the waves' partial dgamma, then dbeta
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            float* __restrict__ gcol, int rows, int d, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [LNB_WAVES][d]: the waves' partial dgamma, then dbeta, then gcol
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  f32x4 gam[NCH], pg[NCH], pb[NCH];
+  // gcol (optional): column sums of gout = the bias gradient of the Linear whose output gradient gout is (the launch is at most
+  // one workgroup per CU, so the third accumulator set costs no occupancy)
+  f32x4 gam[NCH], pg[NCH], pb[NCH], pc[NCH];
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     const int c = ch * 256 + lane * 4;
     gam[ch] = c < d ? load_row4<float>(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-    pg[ch] = pb[ch] = f32x4{0.f, 0.f, 0.f, 0.f};
+    pg[ch] = pb[ch] = pc[ch] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int row_begin = blockIdx.x * rows_per_block;
   const int row_end = min(rows, row_begin + rows_per_block);
@@ -94,6 +96,7 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const DyT
         if (resid) dx += load_row4<float>(resid + base + c);
         store_row4(gout + base + c, dx);
         if (gout_t) store_row4(gout_t + base + c, dx);
+        pc[ch] += dx;
       }
     }
   }
@@ -101,16 +104,18 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const DyT
   // then each thread adds the 8 rows of its columns and issues the one global atomic per column - first dgamma, then dbeta
   // through the same buffer.  (LDS float atomics here - 48 ds_add_f32 per lane from 8 waves on the same addresses - were a
   // 12 us tail of every launch.)
+  const int passes = gcol ? 3 : 2;                   // uniform over the grid
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
+  for (int pass = 0; pass < 3; ++pass) {
+    if (pass >= passes) break;
     if (pass) __syncthreads();
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       const int c = ch * 256 + lane * 4;
-      if (c < d) *reinterpret_cast<f32x4*>(red + wave * d + c) = pass ? pb[ch] : pg[ch];
+      if (c < d) *reinterpret_cast<f32x4*>(red + wave * d + c) = pass == 0 ? pg[ch] : pass == 1 ? pb[ch] : pc[ch];
     }
     __syncthreads();
-    float* out = pass ? dbeta : dgamma;
+    float* out = pass == 0 ? dgamma : pass == 1 ? dbeta : gcol;
     for (int c = threadIdx.x; c < d; c += LNB_WAVES * 64) {
       float t = 0.f;
 #pragma unroll
@@ -559,6 +564,13 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict_
 extern "C" int gpt_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd,
                                  const float* gamma, const float* resid, float* gout, void* gout_t, int gout_t_dtype,
                                  float* dgamma, float* dbeta, int rows, int d, void* stream) {
+  return gpt_layernorm_bwd_colsum(dy, dy_dtype, x, mean, rstd, gamma, resid, gout, gout_t, gout_t_dtype, dgamma, dbeta, nullptr, rows,
+                                  d, stream);
+}
+
+extern "C" int gpt_layernorm_bwd_colsum(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd,
+                                        const float* gamma, const float* resid, float* gout, void* gout_t, int gout_t_dtype,
+                                        float* dgamma, float* dbeta, float* gcol, int rows, int d, void* stream) {
   GPT_REQUIRE(dy && x && mean && rstd && gamma && gout && dgamma && dbeta, "gpt_layernorm_bwd: null operand");
   GPT_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 3072, "gpt_layernorm_bwd: bad sizes (need d %% 4 == 0, d <= 3072)");
   // every workgroup ends with one atomic per column on the SAME 2d addresses: their number, not the streaming, sets the tail
@@ -581,7 +593,7 @@ extern "C" int gpt_layernorm_bwd(const void* dy, int dy_dtype, const float* x, c
       attr_set = true;                                                                                                  \
     }                                                                                                                   \
     hipLaunchKernelGGL((layernorm_bwd_kernel<DY, OUT, NCH>), grid, block, lds, s, (const DY*)dy, x, mean, rstd, gamma, resid, \
-                       gout, (OUT*)gout_t, dgamma, dbeta, rows, d, rpb);                                                \
+                       gout, (OUT*)gout_t, dgamma, dbeta, gcol, rows, d, rpb);                                              \
   } while (0)
 #define LNB_T(NCH)                         \
   do {                                     \

@@ -202,6 +202,10 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
     const char* e = getenv("GPT_WGRAD_TN");   // 0: always transpose + NT kernel (cross-check of the TN kernel)
     return !e || atoi(e) != 0;
   }();
+  static const bool fuse_col = [] {
+    const char* e = getenv("GPT_LNB_COLSUM");   // 0: bias gradients of mlp.2 / attn.proj by separate gpt_colsum launches (cross-check, A/B)
+    return !e || atoi(e) != 0;
+  }();
   auto wgrad = [&](const void* dY, int n_out, const void* X, int k_in, float* gW) -> int {
     // the TN kernel cuts the row range into spans when the weight has few 256 x 256 tiles (gemm256_tn.hip)
     if (use_tn && dt == GPT_BF16 && M % 64 == 0 && n_out % 256 == 0 && k_in % 256 == 0)
@@ -231,8 +235,11 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
     // dW_j[n, :] += sum_b d_out[b, off_j + n] hf[b, j, :]   (M = n_j, N = d, K = B)
     CHECK(gpt_small_gemm_batched(m->n_out_tok, GPT_F32, pa, 1, m->D, dt, ph, (int64_t)T * d, 1, pg, vd, vn, vd, vB, 1, stream));
   }
-  CHECK(gpt_layernorm_bwd(bw->d_tok, GPT_F32, xbuf(2 * L), stat(2 * L + 1, 0), stat(2 * L + 1, 1), m->ln_f_w, nullptr, bw->g, bw->gt, dt,
-                          bw->g_ln_f_w, bw->g_ln_f_b, M, d, stream));
+  // bw->g / bw->gt = gradient of the residual stream behind the last Block = dY of its mlp.2: the bias gradient g_b2 is its column sum,
+  // taken by the LayerNorm backward that produces it (and so for every Block below: ln1's backward of Block l + 1 feeds Block l's mlp.2,
+  // ln2's backward feeds the attention projection of its own Block)
+  CHECK(gpt_layernorm_bwd_colsum(bw->d_tok, GPT_F32, xbuf(2 * L), stat(2 * L + 1, 0), stat(2 * L + 1, 1), m->ln_f_w, nullptr, bw->g, bw->gt,
+                                 dt, bw->g_ln_f_w, bw->g_ln_f_b, fuse_col && L > 0 ? bw->layers[L - 1].g_b2 : nullptr, M, d, stream));
   }
 
   // stages 1 .. L - the blocks, last to first (stage s = layer L - s)
@@ -253,17 +260,17 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
     void* pre = lay(ws->pre, l, 4 * (size_t)d);
     void* gt2 = grouped ? bw->tA : bw->gt;               // dY of the attention projection
     // mlp.2
-    CHECK(gpt_colsum(dt, bw->gt, d, gl.g_b2, M, d, stream));
+    if (!fuse_col) CHECK(gpt_colsum(dt, bw->gt, d, gl.g_b2, M, d, stream));
     if (!grouped) CHECK(wgrad(bw->gt, d, act, 4 * d, gl.g_w2));
     CHECK(gpt_gemm_nt(dt, bw->gt, d, gl.w2_t, d, nullptr, bw->d_act, 4 * d, pre, 4 * d, M, 4 * d, d, GPT_EPI_DGELU, stream));
     // mlp.0
     CHECK(gpt_colsum(dt, bw->d_act, 4 * d, gl.g_b1, M, 4 * d, stream));
     if (!grouped) CHECK(wgrad(bw->d_act, 4 * d, h2, d, gl.g_w1));
     CHECK(gpt_gemm_nt(dt, bw->d_act, 4 * d, gl.w1_t, 4 * d, nullptr, bw->d_h, d, nullptr, 0, M, d, 4 * d, GPT_EPI_STORE, stream));
-    CHECK(gpt_layernorm_bwd(bw->d_h, dt, xbuf(2 * l + 1), stat(2 + 2 * l, 0), stat(2 + 2 * l, 1), ly.ln2_w, bw->g, bw->g, gt2, dt,
-                            gl.g_ln2_w, gl.g_ln2_b, M, d, stream));
+    CHECK(gpt_layernorm_bwd_colsum(bw->d_h, dt, xbuf(2 * l + 1), stat(2 + 2 * l, 0), stat(2 + 2 * l, 1), ly.ln2_w, bw->g, bw->g, gt2, dt,
+                                   gl.g_ln2_w, gl.g_ln2_b, fuse_col ? gl.g_bproj : nullptr, M, d, stream));
     // attention output projection
-    CHECK(gpt_colsum(dt, gt2, d, gl.g_bproj, M, d, stream));
+    if (!fuse_col) CHECK(gpt_colsum(dt, gt2, d, gl.g_bproj, M, d, stream));
     if (!grouped) CHECK(wgrad(gt2, d, att, d, gl.g_wproj));
     CHECK(gpt_gemm_nt(dt, gt2, d, gl.wproj_t, d, nullptr, bw->d_h, d, nullptr, 0, M, d, d, GPT_EPI_STORE, stream));
     CHECK(gpt_attention_bwd(dt, qkv, bw->d_h, bw->d_qkv, B, T, m->n_head, d / m->n_head, stream));
@@ -281,8 +288,8 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
       CHECK(wgrad(bw->d_qkv, 3 * d, h1, d, gl.g_wqkv));
     }
     CHECK(gpt_gemm_nt(dt, bw->d_qkv, 3 * d, gl.wqkv_t, 3 * d, nullptr, bw->d_h, d, nullptr, 0, M, d, 3 * d, GPT_EPI_STORE, stream));
-    CHECK(gpt_layernorm_bwd(bw->d_h, dt, xbuf(2 * l), stat(1 + 2 * l, 0), stat(1 + 2 * l, 1), ly.ln1_w, bw->g, bw->g, bw->gt, dt,
-                            gl.g_ln1_w, gl.g_ln1_b, M, d, stream));
+    CHECK(gpt_layernorm_bwd_colsum(bw->d_h, dt, xbuf(2 * l), stat(1 + 2 * l, 0), stat(1 + 2 * l, 1), ly.ln1_w, bw->g, bw->g, bw->gt, dt,
+                                   gl.g_ln1_w, gl.g_ln1_b, fuse_col && l > 0 ? bw->layers[l - 1].g_b2 : nullptr, M, d, stream));
   }
   if (stage_end < L + 2) return 0;
   // stage L + 1 - position embedding: sum over the batch of the gradient of x0 = ln_in(enc) + pos_emb

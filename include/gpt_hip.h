@@ -203,6 +203,12 @@ int gpt_transpose(int dtype, const void* src, void* dst, int rows, int cols, int
 int gpt_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd,
                       const float* gamma, const float* resid, float* gout, void* gout_t, int gout_t_dtype,
                       float* dgamma, float* dbeta, int rows, int d, void* stream);
+/* Same, and gcol (fp32 [d], optional) ACCUMULATES the column sums of gout: gout is the output gradient of the Linear that
+ * feeds the residual stream there (mlp.2 / attn.proj, transformer.py:66-70), so gcol is that Linear's bias gradient and the
+ * separate gpt_colsum pass over gout_t is not needed. */
+int gpt_layernorm_bwd_colsum(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd,
+                             const float* gamma, const float* resid, float* gout, void* gout_t, int gout_t_dtype,
+                             float* dgamma, float* dbeta, float* gcol, int rows, int d, void* stream);
 /* dqkv[B*T,3d] from qkv[B*T,3d] and dy[B*T,d] (gradient of the attention output), all `dtype`. */
 int gpt_attention_bwd(int dtype, const void* qkv, const void* dy, void* dqkv, int B, int T, int n_head, int hd,
                       void* stream);

@@ -59,6 +59,14 @@ def test_layernorm_backward(d, dy_dtype):
     assert rel_err(gout.cpu() - resid, xr.grad) < 2e-5
     assert rel_err(gt.float().cpu(), gout.cpu()) < 1e-2
     assert rel_err(dg.cpu(), wr.grad) < 2e-5 and rel_err(db.cpu(), br.grad) < 2e-5
+    # the variant that also accumulates the column sums of gout (the bias gradient of the Linear behind the residual add)
+    gout2, gt2 = torch.empty_like(gout), torch.empty_like(gt)
+    dg2, db2, gcol = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV), torch.ones(d, device=DEV)
+    L.check(L.lib().gpt_layernorm_bwd_colsum(L.ptr(dy_d), code, L.ptr(xd), L.ptr(mean), L.ptr(rstd), L.ptr(wd), L.ptr(rd), L.ptr(gout2),
+                                             L.ptr(gt2), L.BF16, L.ptr(dg2), L.ptr(db2), L.ptr(gcol), rows, d, L.stream()), "ln_bwd_colsum")
+    assert torch.equal(gout2, gout) and torch.equal(gt2, gt)
+    assert rel_err(dg2.cpu(), wr.grad) < 2e-5 and rel_err(db2.cpu(), br.grad) < 2e-5
+    assert rel_err(gcol.cpu() - 1, gout.cpu().double().sum(0)) < 2e-5
 
 
 def test_small_gemm_colsum_transpose():
