@@ -9,7 +9,7 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
  *   - `dtype` selects the activation/weight type of the MFMA contractions:
  *        GPT_F32  = exact fp32 (v_mfma_f32_32x32x2_f32), the parity mode,
- *        GPT_BF16 = bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16);
+ *        GPT_BF16 = bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16);
  *     residual stream, LayerNorm/softmax statistics, biases and all DDPM arithmetic are fp32 in both;
  *   - return value: 0 = ok; negative = rejected before any launch (bad shape / alignment / enum);
  *     positive = a hipError_t from the launch.  gpt_last_error() gives the message.
@@ -41,8 +41,9 @@ int gpt_abi_version(void);
 
 /* C[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N]).  A, W: `dtype`, row-major, leading dims lda/ldw in
  * elements, K % 64 == 0 (bf16) or K % 32 == 0 (fp32), 16-byte aligned rows; N % 8 == 0, ldc % 4 == 0, C/aux/bias
- * 16-byte aligned (vector epilogue).  bias: fp32 or NULL.  In bf16 mode GELU uses a 1.5e-7-accurate erf
- * polynomial (far below bf16 output rounding); fp32 mode uses erff.
+ * 16-byte aligned (vector epilogue).  bias: fp32 or NULL.  GELU: fp32 mode uses libm erff (parity mode); bf16 mode uses
+ * x * sigmoid(a x + b x^3 + c x^5) fitted to the exact erf GELU, |error| <= 2.6e-5 absolute (below the bf16 rounding of the
+ * output; csrc/gemm_common.h gelu_fast2), and its derivative (GPT_EPI_DGELU) a 1.5e-7-accurate erf polynomial.
  * Replaces nn.Linear on the path: Gpt/models/transformer.py:38-40 (q,k,v), :50 (proj), :63-65 (mlp). */
 int gpt_gemm_nt(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                 void* C, int64_t ldc, void* aux, int64_t ldaux, int M, int N, int K, int epilogue,
