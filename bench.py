@@ -97,7 +97,7 @@ class SampleRunner:
             self.cursor = last - 1 if last > 0 else n - 1
 
 
-def cpu_baseline(case, seconds_target=15.0):
+def cpu_baseline(case, seconds_target=20.0):
     """The oracle's denoising step (forward + posterior update) on the host cores, bounded sample."""
     from oracle import denoiser as od, diffusion as odf
     c = CASES[case]
@@ -106,7 +106,7 @@ def cpu_baseline(case, seconds_target=15.0):
                    c["split_policy"], True)
     sd = od.random_state_dict(plan, seed=0)
     tb = odf.Tables(1000)
-    B = 16
+    B = 64                                   # the CPU reference is timed at B = 64
     g = torch.Generator().manual_seed(1)
     x, xp = torch.randn(B, plan.D, generator=g), torch.randn(B, plan.D, generator=g) * 0.538
     lt, lp = torch.zeros(B), 0.3 + 2.1 * torch.rand(B, generator=g)
@@ -122,7 +122,7 @@ def cpu_baseline(case, seconds_target=15.0):
     t0 = time.perf_counter()
     step(998)
     one = time.perf_counter() - t0
-    reps = max(2, min(100, int(seconds_target / max(one, 1e-3))))     # a bounded sample: about 15 s of CPU work
+    reps = max(2, min(100, int(seconds_target / max(one, 1e-3))))     # a bounded sample: about 20 s of CPU work
     t0 = time.perf_counter()
     for i in range(reps):
         x = step(997 - i)
@@ -149,6 +149,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the short training-step measurement ('train' object)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the short fp32 / cifar sampling measurements ('fp32', 'cifar' objects)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region of --steps steps is run this many times: `value` is the FIRST (the contract's region), "
+                         "`spread` reports median / min / max over all of them")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -165,6 +169,9 @@ def main():
         line = bench_train(args, device, world, rank)
     else:
         line = bench_sample(args, device, world, rank)
+        if not args.no_extra and (args.case, args.dtype) == ("mnist", "bf16"):
+            line["fp32"] = secondary_sample(args, device, world, rank, line, "fp32", "mnist", "fp32", args.batch or 320, 20, 3)
+            line["cifar"] = secondary_sample(args, device, world, rank, line, "cifar", "cifar", "bf16", 1280, 20, 3)
         if not args.no_train:
             line["train"] = guarded_train(args, device, world, rank, line, "train", max(1, 1024 // world), "strong")
             # efficiency also at a fixed per-GPU batch: 128 pairs per GPU (the 8-GPU share of 1024) at every N
@@ -177,24 +184,40 @@ def main():
         dist.destroy_process_group()
 
 
-def guarded_train(args, device, world, rank, line, key, batch, scaling, limit_s=150.0):
-    """BASELINE.json's second metric (train iters/sec, configs[3]) measured briefly after the headline, 10 timed steps:
-    "train" at global batch 1024 = int(1024 / N) pairs per GPU as configs/train/mnist_loss.yaml runs it (strong scaling),
-    "train_weak" at 128 pairs per GPU for every N.
-    A watchdog prints the headline line without it if the step does not finish (the line must never be lost)."""
+def guarded(fn, rank, line, key, limit_s):
+    """Runs a secondary measurement under a watchdog.  If it does not finish within limit_s the headline line is printed
+    with an error object under `key` (the line must never be lost), every thread's stack goes to stderr so that the hang
+    can be root-caused, and the process exits NON-ZERO: a hung GPU step must not look like a successful run."""
+    import faulthandler
     import threading
-    from gpt_amd.trainstep import bench_train
 
     def give_up():
         if rank == 0:
-            line[key] = {"error": f"training step did not finish within {limit_s:.0f} s"}
+            line[key] = {"error": f"did not finish within {limit_s:.0f} s (hung step or collective): process aborted, exit code 3"}
             print(json.dumps(line), flush=True)
-        os._exit(0)
+        sys.stderr.write(f"bench.py: '{key}' measurement exceeded {limit_s:.0f} s; stacks follow\n")
+        faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+        sys.stderr.flush()
+        os._exit(3)
 
     timer = threading.Timer(limit_s, give_up)
     timer.daemon = True
     timer.start()
     try:
+        return fn()
+    except Exception as e:  # noqa: BLE001 - the headline line must survive a failure of a secondary measurement
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        timer.cancel()
+
+
+def guarded_train(args, device, world, rank, line, key, batch, scaling, limit_s=150.0):
+    """BASELINE.json's second metric (train iters/sec, configs[3]) measured briefly after the headline, 10 timed steps:
+    "train" at global batch 1024 = int(1024 / N) pairs per GPU as configs/train/mnist_loss.yaml runs it (strong scaling),
+    "train_weak" at 128 pairs per GPU for every N."""
+    from gpt_amd.trainstep import bench_train
+
+    def run():
         targs = argparse.Namespace(**vars(args))
         targs.steps, targs.warmup, targs.batch = 10, 3, batch
         res = bench_train(targs, device, world, rank)
@@ -203,10 +226,25 @@ def guarded_train(args, device, world, rank, line, key, batch, scaling, limit_s=
         out.update(metric=res["metric"], scaling=scaling, global_batch=res["config"]["global_batch"],
                    batch_per_gpu=res["config"]["batch_per_gpu"], workload=res["config"]["workload"])
         return out
-    except Exception as e:  # noqa: BLE001 - the headline line must survive a failure of the secondary measurement
-        return {"error": f"{type(e).__name__}: {e}"}
-    finally:
-        timer.cancel()
+
+    return guarded(run, rank, line, key, limit_s)
+
+
+def secondary_sample(args, device, world, rank, line, key, case, dtype, batch, steps, warmup, limit_s=150.0):
+    """The other stated sampling configurations as short objects of the same line (each with its own roofline):
+    `fp32` = configs[1]'s fp32 leg (mnist shapes, B = 320), `cifar` = configs[2] at N = 1 (CIFAR-10 shapes, B = 1280, bf16)."""
+    def run():
+        sargs = argparse.Namespace(**vars(args))
+        sargs.case, sargs.dtype, sargs.batch, sargs.steps, sargs.warmup, sargs.repeats = case, dtype, batch, steps, warmup, 1
+        res = bench_sample(sargs, device, world, rank, cpu=False)
+        keep = ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "denoiser_tflops_per_gpu", "roofline")
+        out = {k: res[k] for k in keep if k in res}
+        out.update(metric=res["metric"], workload=res["config"]["workload"], batch_per_gpu=batch)
+        return out
+
+    out = guarded(run, rank, line, key, limit_s)
+    torch.cuda.empty_cache()
+    return out
 
 
 def pmc_traffic(case, B, dtype):
@@ -240,7 +278,7 @@ def sync_all(world):
     torch.cuda.synchronize()
 
 
-def bench_sample(args, device, world, rank):
+def bench_sample(args, device, world, rank, cpu=True):
     case, B = args.case, args.batch or 320
     model = make_model(case, args.dtype, device)
     diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
@@ -263,18 +301,32 @@ def bench_sample(args, device, world, rank):
         elapsed = float(tmax.item())
     assert local_rows.shape == (B * world, D) and bool(torch.isfinite(runner.x).all())
     ms_per_step = elapsed * 1e3 / args.steps
+    # the same region again (no gather): one number says nothing about its own spread
+    regions = [ms_per_step]
+    for _ in range(max(0, getattr(args, "repeats", 1) - 1)):
+        sync_all(world)
+        t1 = time.perf_counter()
+        runner.run(args.steps)
+        sync_all(world)
+        regions.append((time.perf_counter() - t1) * 1e3 / args.steps)
     vectors_per_s = B * world / (ms_per_step * 1e-3 * diff.num_timesteps)
     fwd_flops = flops_per_forward(case) * B
     line = {
         "metric": "sampled param-vectors/sec (DDPM)", "value": vectors_per_s, "unit": "vectors/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"{case}_loss G.pt shapes (D={D}, n_embd={CASES[case]['n_embd']}, 12 layers, 26 tokens), "
+        "config": {"workload": f"{'mnist_loss' if case == 'mnist' else 'cifar10_error' if case == 'cifar' else case} G.pt shapes "
+                               f"(D={D}, n_embd={CASES[case]['n_embd']}, {CASES[case]['n_layer']} layers, 26 tokens), "
                                f"1000-step DDPM p_sample_loop, B={B} vectors per GPU, random-init weights, "
                                f"in-kernel Philox noise; step = 1 reverse-diffusion step",
                    "batch_per_gpu": B, "diffusion_steps": diff.num_timesteps},
         "denoiser_tflops_per_gpu": fwd_flops / (ms_per_step * 1e-3) / 1e12,
     }
+    if len(regions) > 1:
+        srt = sorted(regions)
+        line["spread"] = {"regions": len(regions), "steps_each": args.steps, "ms_per_step_median": srt[len(srt) // 2],
+                          "ms_per_step_min": srt[0], "ms_per_step_max": srt[-1],
+                          "note": "rank-local times of the same timed region repeated; `value` is the first region"}
     if not args.no_roofline:
         lib = L.lib()
         sync_all(world)
@@ -291,7 +343,7 @@ def bench_sample(args, device, world, rank):
                             "kernel": "gemm256_kernel + gemm_nt_kernel K spans of fc1's row tail (qkv/proj/fc1/fc2 contractions, 5 GEMM calls per layer)", "launches": nl.value,
                             "avg_launch_us": ms.value * 1e3 / max(nl.value, 1),
                             "flops_per_launch": fl.value / max(nl.value, 1)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if cpu and rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(case)
     return line
 

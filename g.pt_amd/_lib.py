@@ -50,6 +50,11 @@ class OptSegment(C.Structure):
                 ("reserved", i32)]
 
 
+class PackItem(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("first4", i64), ("count", i64), ("k", i32), ("ld", i32), ("dst_dtype", i32),
+                ("reserved", i32)]
+
+
 class Workspace(C.Structure):
     _fields_ = [("B_max", i32), ("layer_stride", i32)] + \
                [(n, vp) for n in ("scal", "enc", "x", "h1", "qkv", "att", "h2", "pre", "act", "hf", "stats")]
@@ -106,6 +111,7 @@ _PROTOS = {
     "gpt_adamw_ema_step": ([vp, vp, vp, vp, vp, vp, i32, vp, i32, i64, vp, f32, f32, f64, f64, f64, f64, f64, i32, f64,
                             i32, vp], i32),
     "gpt_pack_segments": ([vp, vp, i32, vp, i32, i64, vp], i32),
+    "gpt_pack_tensors": ([vp, i32, i64, vp], i32),
     "gpt_sample_loop": ([C.POINTER(Model), C.POINTER(Workspace), vp, vp, vp, i32, vp, vp, C.POINTER(i64), i32, i32,
                          i32, i32, i32, f32, f32, vp, u64, vp, vp, vp, vp, i32, vp], i32),
     "gpt_ddim_sample_loop": ([C.POINTER(Model), C.POINTER(Workspace), vp, vp, vp, i32, vp, vp, vp, f32, C.POINTER(i64), i32,

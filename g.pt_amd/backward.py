@@ -146,6 +146,7 @@ def forward_keep(model, x, t, lt, lp, x_prev):
     _ensure_training_state(eng)
     B = x.shape[0]
     ws = eng.workspace(B, keep_activations=True)
+    eng.keep_gen += 1
     out = torch.empty_like(x)
     L.check(L.lib().gpt_denoiser_forward(C.byref(eng.cmodel), C.byref(ws), L.ptr(x), L.ptr(t), L.ptr(lt), L.ptr(lp),
                                          int(lt.dtype == torch.float64), L.ptr(x_prev), L.ptr(out), B, L.stream()),
@@ -184,14 +185,23 @@ class DenoiseFunction(torch.autograd.Function):
         eng, ws, out = forward_keep(model, x, t, lt, lp, x_prev)
         ctx.model, ctx.eng, ctx.ws = model, eng, ws
         ctx.save_for_backward(x, x_prev)
-        ctx.sig = eng.sig
+        # The kept activations live in the engine's ONE training workspace: a second grad-enabled forward of the same model
+        # before this call's backward overwrites them (or re-allocates them for a larger batch).  The generation counter
+        # turns that into an error instead of silently wrong gradients; the buffers stay referenced from ctx so that a
+        # re-allocation cannot free memory this backward's descriptor still points at.
+        ctx.keep_gen, ctx.bufs = eng.keep_gen, eng.buffers(keep_activations=True)
+        ctx.versions = tuple(p._version for p in model.parameters())
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         x, x_prev = ctx.saved_tensors
         eng = ctx.eng
-        if eng.sig != ctx.sig:
+        if eng.keep_gen != ctx.keep_gen:
+            raise RuntimeError("Gpt: another grad-enabled forward of this model ran before this backward; the HIP path keeps the "
+                               "activations of ONE pending forward per model (call backward() after each forward, as "
+                               "main.py:47-67 does)")
+        if ctx.versions != tuple(p._version for p in ctx.model.parameters()):
             raise RuntimeError("G.pt parameters changed between forward and backward")
         buf = eng.arena.new_buffer()
         backward_into(eng, ctx.ws, x, x_prev, d_out.detach().float().contiguous(), buf)

@@ -145,7 +145,44 @@ __global__ __launch_bounds__(OPT_THREADS) void pack_kernel(const float* __restri
   if (sg.packed_off >= 0) write_packed(packed, packed_dtype, sg, i4 * 4, reinterpret_cast<const f32x4*>(params)[i4]);
 }
 
+// Multi-tensor variant for parameters that do NOT live in one arena (the checkpoint-layout nn.Module of the reference: 235
+// separate tensors): item i covers 16-byte groups [first4, next item's first4) of a virtual concatenation.
+__global__ __launch_bounds__(OPT_THREADS) void pack_tensors_kernel(const gpt_pack_item_t* __restrict__ items, int n_items, int64_t n4) {
+  const int64_t i4 = (int64_t)blockIdx.x * OPT_THREADS + threadIdx.x;
+  if (i4 >= n4) return;
+  int lo = 0, hi = n_items - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].first4 <= i4) lo = mid; else hi = mid - 1;
+  }
+  const gpt_pack_item_t it = items[lo];
+  const int64_t r = (i4 - it.first4) * 4;
+  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (r + 4 <= it.count) {
+    v = *reinterpret_cast<const f32x4*>(it.src + r);
+  } else {
+    for (int j = 0; j < 4 && r + j < it.count; ++j) v[j] = it.src[r + j];
+  }
+  gpt_opt_segment_t sg;
+  sg.start = 0; sg.count = it.count; sg.packed_off = 0; sg.k = it.k; sg.ld = it.ld; sg.decay = 0; sg.reserved = 0;
+  if (it.k == it.ld && r + 4 > it.count) {          // ragged tail of a plain copy: element by element
+    for (int j = 0; j < 4 && r + j < it.count; ++j) {
+      if (it.dst_dtype == GPT_BF16) reinterpret_cast<bf16_t*>(it.dst)[r + j] = f32_to_bf16(v[j]);
+      else reinterpret_cast<float*>(it.dst)[r + j] = v[j];
+    }
+    return;
+  }
+  write_packed(it.dst, it.dst_dtype, sg, r, v);
+}
+
 }  // namespace
+
+extern "C" int gpt_pack_tensors(const gpt_pack_item_t* items, int n_items, int64_t n4, void* stream) {
+  GPT_REQUIRE(items && n_items > 0 && n4 > 0, "gpt_pack_tensors: bad operands");
+  const int64_t blocks = (n4 + OPT_THREADS - 1) / OPT_THREADS;
+  hipLaunchKernelGGL(pack_tensors_kernel, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, (hipStream_t)stream, items, n_items, n4);
+  return gpt_launch_status("gpt_pack_tensors");
+}
 
 extern "C" int gpt_grad_sumsq(const float* grads, int64_t n, float* scratch, float* out, void* stream) {
   GPT_REQUIRE(grads && scratch && out && n > 0 && n % 4 == 0, "gpt_grad_sumsq: need n %% 4 == 0 and non-null buffers");

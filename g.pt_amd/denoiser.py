@@ -188,47 +188,84 @@ def _round_up(n, m):
 class _Engine:
     """Packed device weights + activation workspace of one (model, device, compute dtype).
 
-    Packed copies (fused [query|key|value] weight, bf16 casts, K-padded encoder weights) are derived from
-    the checkpoint-layout parameters and refreshed whenever a parameter's version counter changes
-    (an optimizer step, load_state_dict, EMA update)."""
+    Packed copies (fused [query|key|value] weight and bias, bf16 casts, K-padded encoder weights) live in buffers allocated
+    once per parameter layout and are RE-DERIVED from the live parameters on every `Gpt.engine()` call - one launch
+    (gpt_pack_tensors, or gpt_pack_segments for a flat arena), i.e. once per forward / per sampling loop.  torch's version
+    counters cannot be trusted for this: the reference's EMA update writes through `.data` (Gpt/utils.py:146-152), which
+    does not bump them.  Only an owner that rewrites the packed operands itself together with the parameters (the fused
+    optimizer pass of TrainStep) sets `managed` and calls `touched()` instead."""
 
     def __init__(self, model, device, code):
         self.model, self.device, self.code = model, device, code
         self.tdtype = L.torch_dtype(code)
-        self.sig = None
+        self.struct = None          # parameter layout the pointer tables were built for
+        self.gen = 0                # bumped whenever the packed operands were re-derived (or rewritten by the owner)
+        self.managed = False
+        self._versions = None
+        self.keep_gen = 0           # bumped by every training forward (backward.py: one pending backward per engine)
         self.keep = []
         self.cmodel = None
+        self.items = None
         self.ws = {}
         L.ensure_gemm_workspace(device)
 
     # ---- weights
-    def _signature(self):
-        return (self.model._weights_epoch,) + tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+    @property
+    def sig(self):
+        return (self.struct, self.gen)
 
-    def _cast(self, w):
-        w = w.detach()
-        if self.code == L.F32:
-            return w.contiguous()
-        out = torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
-        wc = w.contiguous()
-        L.check(L.lib().gpt_f32_to_bf16(L.ptr(wc), L.ptr(out), wc.numel(), L.stream()), "gpt_f32_to_bf16")
-        return out
+    def touched(self):
+        """The owner rewrote parameters and packed operands together (TrainStep.update)."""
+        self.gen += 1
+
+    def _structure(self, flat):
+        return (id(flat) if flat is not None else 0,) + tuple(p.data_ptr() for p in self.model.parameters())
 
     def refresh(self):
-        sig = self._signature()
-        if sig == self.sig:
-            return
+        m = self.model
+        flat = getattr(m, "_flat", None)
+        if flat is not None and not flat.bound(m):
+            flat = m._flat = None
+        st = self._structure(flat)
+        if st != self.struct:
+            self._build(flat)
+            self.struct = st
+        elif self.managed and self._versions == tuple(p._version for p in m.parameters()):
+            return                  # (a load_state_dict / optimizer.step behind the owner's back still shows in the counters)
+        self._repack(flat)
+
+    def _repack(self, flat):
+        if flat is not None:
+            flat.repack(self.code)
+        else:
+            table, n_items, n4 = self.items
+            L.check(L.lib().gpt_pack_tensors(L.ptr(table), n_items, n4, L.stream()), "gpt_pack_tensors")
+        self._versions = tuple(p._version for p in self.model.parameters())
+        self.gen += 1
+
+    def _build(self, flat):
         m, dec = self.model, self.model.decoder
         for p in m.parameters():
             if p.device != self.device or p.dtype != torch.float32:
                 raise L.GptHipError("all G.pt parameters must be fp32 tensors on one GPU")
-        keep = []
-        # parameters living in a flat arena (g.pt_amd/flat.py): the operands are the arena / its packed copy
-        flat = getattr(m, "_flat", None)
-        if flat is not None and not flat.bound(m):
-            flat = m._flat = None
-        if flat is not None:
-            flat.repack(self.code)
+            if not p.is_contiguous() or p.data_ptr() % 16:
+                raise L.GptHipError("G.pt parameters must be contiguous, 16-byte aligned tensors")
+        keep, items = [], []
+        dev, td, bf = self.device, self.tdtype, self.code == L.BF16
+
+        def packed(src, dst=None, k=None, ld=None, dtype=None):
+            """A packed copy of parameter `src` (re-derived by _repack); returns the destination tensor."""
+            if dst is None:
+                dst = torch.empty(src.shape, dtype=dtype or td, device=dev)
+                keep.append(dst)
+            items.append((src, dst, k or 1, ld or 1))
+            return dst
+
+        def operand(w):
+            """GEMM operand of a Linear weight: the live fp32 parameter in fp32 mode, a bf16 copy in bf16 mode."""
+            return L.ptr(packed(w)) if bf else L.ptr(w)
+
+        d = dec.n_embd
         layers = (L.Layer * dec.n_layer)()
         for l, blk in enumerate(dec.blocks):
             a = blk.attn
@@ -241,12 +278,14 @@ class _Engine:
                 ly.wproj = flat.weight_ptr(self.code, pre + "attn.proj.weight")
                 ly.w1, ly.w2 = flat.weight_ptr(self.code, pre + "mlp.0.weight"), flat.weight_ptr(self.code, pre + "mlp.2.weight")
             else:
-                wqkv = self._cast(torch.cat([a.query.weight, a.key.weight, a.value.weight], 0))
-                bqkv = torch.cat([a.query.bias, a.key.bias, a.value.bias], 0).detach().contiguous()
-                wproj, w1, w2 = self._cast(a.proj.weight), self._cast(blk.mlp[0].weight), self._cast(blk.mlp[2].weight)
-                keep += [wqkv, bqkv, wproj, w1, w2]
+                wqkv = torch.empty(3 * d, d, dtype=td, device=dev)
+                bqkv = torch.empty(3 * d, dtype=torch.float32, device=dev)
+                keep += [wqkv, bqkv]
+                for i, lin in enumerate((a.query, a.key, a.value)):
+                    packed(lin.weight, wqkv[i * d:(i + 1) * d])
+                    packed(lin.bias, bqkv[i * d:(i + 1) * d])
                 ly.wqkv, ly.bqkv = L.ptr(wqkv), L.ptr(bqkv)
-                ly.wproj, ly.w1, ly.w2 = L.ptr(wproj), L.ptr(w1), L.ptr(w2)
+                ly.wproj, ly.w1, ly.w2 = operand(a.proj.weight), operand(blk.mlp[0].weight), operand(blk.mlp[2].weight)
             ly.bproj, ly.b1, ly.b2 = L.ptr(a.proj.bias), L.ptr(blk.mlp[0].bias), L.ptr(blk.mlp[2].bias)
         cm = L.Model()
         cm.dtype, cm.d, cm.n_head, cm.n_layer = self.code, dec.n_embd, dec.n_head, dec.n_layer
@@ -261,11 +300,10 @@ class _Engine:
             if flat is not None:
                 wptr = flat.enc_ptr(self.code, i)
             else:
-                w = dec.input_parameter_projections[i][0].weight.detach()
-                wp = torch.zeros(w.shape[0], kp, dtype=torch.float32, device=self.device)
-                wp[:, :k] = w
-                wp = self._cast(wp)
+                w = dec.input_parameter_projections[i][0].weight
+                wp = torch.zeros(w.shape[0], kp, dtype=td, device=dev)          # K padding stays zero: only [:, :k] is rewritten
                 keep.append(wp)
+                packed(w, wp, k, kp)
                 wptr = L.ptr(wp)
             cm.enc_w[i], cm.enc_w_ld[i], cm.enc_k[i], cm.enc_src[i], cm.enc_off[i] = wptr, kp, k, kind, off
         off = 0
@@ -273,14 +311,24 @@ class _Engine:
             if flat is not None:
                 wptr = flat.weight_ptr(self.code, f"decoder.output_parameter_projections.{j}.0.weight")
             else:
-                w = self._cast(dec.output_parameter_projections[j][0].weight)
-                keep.append(w)
-                wptr = L.ptr(w)
+                wptr = operand(dec.output_parameter_projections[j][0].weight)
             cm.dec_w[j], cm.dec_n[j], cm.dec_off[j] = wptr, n, off
             off += n
         cm.layers = C.cast(layers, C.POINTER(L.Layer))
         keep.append(layers)
-        self.keep, self.cmodel, self.sig = keep, cm, sig
+        self.items = None
+        if flat is None:
+            arr = (L.PackItem * len(items))()
+            first4 = 0
+            for it, (src, dst, k, ld) in zip(arr, items):
+                it.src, it.dst, it.first4, it.count = L.ptr(src), L.ptr(dst), first4, src.numel()
+                it.k, it.ld, it.dst_dtype = k, ld, L.BF16 if dst.dtype == torch.bfloat16 else L.F32
+                assert it.dst % 16 == 0
+                first4 += (src.numel() + 3) // 4
+            import numpy as np
+            table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dev)
+            self.items = (table, len(items), first4)
+        self.keep, self.cmodel = keep, cm
 
     # ---- activations
     def workspace(self, B, keep_activations=False):
@@ -350,7 +398,6 @@ class Gpt(nn.Module):
         self.token_sources = self._token_sources(num_frequencies)
         self._compute_dtype = os.environ.get("GPT_AMD_DTYPE", "fp32")
         self._engines = {}
-        self._weights_epoch = 0          # bumped by writers that bypass torch's version counters (the fused step)
         self._flat = None                # g.pt_amd/flat.py: FlatState once the parameters live in one arena
 
     # engines hold device pointers: never copy or pickle them with the module

@@ -46,14 +46,25 @@ def scaled_all_reduce(cfg, tensors):
         dist.all_reduce(tensors[0])
         tensors[0].mul_(1.0 / cfg.num_gpus)
         return tensors
-    flat = torch.cat([t.reshape(-1).float() for t in tensors])
-    dist.all_reduce(flat)
-    flat.mul_(1.0 / cfg.num_gpus)
-    off = 0
+    # one flat message per dtype: every tensor is reduced and scaled in its OWN dtype, as the reference's per-tensor
+    # all_reduce + mul_ does (float64 meters stay float64); non-float tensors take the reference's per-tensor route, with its behaviour
+    by_dtype = {}
     for t in tensors:
-        n = t.numel()
-        t.copy_(flat[off:off + n].view_as(t))
-        off += n
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for dtype, group in by_dtype.items():
+        if not dtype.is_floating_point or len(group) == 1:
+            for t in group:
+                dist.all_reduce(t)
+                t.mul_(1.0 / cfg.num_gpus)
+            continue
+        flat = torch.cat([t.reshape(-1) for t in group])
+        dist.all_reduce(flat)
+        flat.mul_(1.0 / cfg.num_gpus)
+        off = 0
+        for t in group:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
     return tensors
 
 

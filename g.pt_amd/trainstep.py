@@ -70,6 +70,7 @@ class TrainStep:
                 p.requires_grad = False
         self.flat_ema = FlatState(self.ema, self.device) if use_ema else None
         self.eng = model.engine(self.device)
+        self.eng.managed = fused            # the fused pass rewrites the packed operands with the parameters
         _ensure_training_state(self.eng)
         self.code = self.eng.code
         self.arena = self.flat.arena
@@ -185,11 +186,9 @@ class TrainStep:
             L.ptr(self.flat_ema.params) if self.flat_ema is not None else None, L.ptr(packed), self.code, L.ptr(seg), n_seg,
             n, L.ptr(self.grad_norm_sq), float(self.grad_clip), 1.0 / self.world, self.lr, self.betas[0], self.betas[1],
             self.eps, self.wd, self.iteration, self.ema_decay, 1, st), "gpt_adamw_ema_step")
-        # the step wrote the parameters, the EMA and this engine's operands behind torch's back
-        model._weights_epoch += 1
-        if self.ema is not None:
-            self.ema._weights_epoch += 1
-        self.eng.sig = self.eng._signature()
+        # the step wrote the parameters and this engine's packed operands together, behind torch's back (the EMA copy's own
+        # engines re-derive their operands on every use: denoiser.py _Engine.refresh)
+        self.eng.touched()
         # transposed dgrad operands of the new weights: needed by the NEXT backward only, so the 48 transposes run on a side
         # stream beside the next forward (memory-bound beside MFMA-bound; 0.9 ms of an 18 ms step at B = 128 otherwise)
         if os.environ.get("GPT_TRAIN_SIDE_STREAM", "1") == "0":      # A/B measurements

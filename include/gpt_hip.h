@@ -52,7 +52,8 @@ int gpt_gemm_nt(int dtype, const void* A, int64_t lda, const void* W, int64_t ld
 /* Optional scratch for gpt_gemm_nt (bf16): with a device buffer registered, problems of few 256 x 256 output tiles and a
  * long K (small batches) are contracted in K spans - fp32 partial tiles into this buffer, then one streaming pass that
  * sums them and applies the epilogue - instead of leaving most CUs idle.  The buffer stays the caller's (the library
- * never allocates); it must outlive the calls, and calls that use it must not overlap on different streams.
+ * never allocates); it must outlive the calls, and calls that use it must not overlap on different streams.  The
+ * registration is per device: it applies to the device that is current at the call.
  * 64 MiB covers the G.pt shapes.  (NULL, 0) unregisters.  No counterpart in the reference (an ATen/cuBLAS internal). */
 int gpt_gemm_set_workspace(void* ptr, size_t bytes);
 
@@ -408,6 +409,21 @@ int gpt_adamw_ema_step(float* params, float* grads, float* exp_avg, float* exp_a
 /* The packed copies alone (after load_state_dict or any other write to the parameters that bypasses the step). */
 int gpt_pack_segments(const float* params, void* packed, int packed_dtype, const gpt_opt_segment_t* segments,
                       int n_segments, int64_t n, void* stream);
+
+/* The same copies for parameters held as SEPARATE tensors (the reference's nn.Module keeps 235 of them): one
+ * launch over a DEVICE table of items.  Item i: `count` fp32 elements at src (16-byte aligned) are written to dst (16-byte
+ * aligned) as dst_dtype (GPT_F32 / GPT_BF16), element j at dst[(j / k) * ld + j % k] (k == ld: a plain cast copy; ld > k: rows
+ * zero-padded by the caller, the K-padded encoder operands).  first4 = the sum of ceil(count / 4) over the items before it;
+ * n4 = that sum over all items.  Used by the Python engine to re-derive its packed operands (fused query|key|value weight and
+ * bias, bf16 copies) from the live parameters before every forward / sampling loop, because writers such as the reference's
+ * EMA update (Gpt/utils.py:146-152: par.data.mul_().add_()) are invisible to torch's version counters. */
+typedef struct {
+  const float* src;
+  void* dst;
+  int64_t first4, count;
+  int32_t k, ld, dst_dtype, reserved;
+} gpt_pack_item_t;
+int gpt_pack_tensors(const gpt_pack_item_t* items, int n_items, int64_t n4, void* stream);
 
 #ifdef __cplusplus
 }

@@ -58,6 +58,12 @@ def _body_helpers(rank):
     res = dp.scaled_all_reduce(cfg, [a, b])
     assert res[0] is a and res[1] is b
     assert torch.allclose(a, torch.full((3,), 1.5)) and torch.allclose(b, torch.full((2, 2), 15.0))
+    # mixed dtypes keep their own dtype and precision (float64 meters are not squeezed through fp32)
+    d64 = torch.tensor([1.0 + 2.0 ** -40 * (rank + 1)], dtype=torch.float64)
+    f32, f32b = torch.tensor([float(rank)]), torch.tensor([4.0 * rank, 8.0])
+    dp.scaled_all_reduce(cfg, [d64, f32, f32b])
+    assert d64.dtype == torch.float64 and float(d64) == 1.0 + 1.5 * 2.0 ** -40
+    assert float(f32) == 0.5 and f32b.tolist() == [2.0, 8.0]
     one = [torch.tensor([2.0 * rank])]
     dp.scaled_all_reduce(cfg, one)
     assert float(one[0]) == 1.0

@@ -149,7 +149,9 @@ def test_gemm_split_k_workspace(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,inplace", [(1664, 1536, 1536, True), (1664, 1536, 6144, False), (3328, 1536, 1536, False),
-                                            (1700, 2048, 2048, True), (8320, 1536, 1536, True), (520, 264, 2048, False)])
+                                            (1700, 2048, 2048, True), (8320, 1536, 1536, True), (520, 264, 2048, False),
+                                            # configs[4] (n_embd 3072) at its per-GPU batch 68: M = 1768, proj and mlp.2
+                                            (1768, 3072, 3072, True), (1768, 3072, 12288, False)])
 def test_gemm_resadd_layernorm(M, N, K, inplace):
     """Residual Linear + the LayerNorm behind it in one call: against fp64, and against the two separate entry points (the
     fused K-span pass at small batches, the two-kernel route at M = 8320 and for widths the fused pass does not cover)."""
