@@ -33,7 +33,7 @@ def _oracle_grads(sd, plan, xp, x_start, lp, lt, t, noise):
     mse, _, _ = odf.training_mse(tb, lambda x, tm: od.forward(sdg, plan, x, tm, lt, lp, xp), x_start, t, noise)
     loss = mse.mean()
     loss.backward()
-    return float(loss), mse.detach(), {k: v.grad for k, v in sdg.items() if k != "scalar_embedder.frequencies"}
+    return float(loss.detach()), mse.detach(), {k: v.grad for k, v in sdg.items() if k != "scalar_embedder.frequencies"}
 
 
 def _compare_grads(got, ref, max_bar, cos_bar):
@@ -241,4 +241,5 @@ def test_second_training_forward_before_backward_is_an_error():
     m.zero_grad(set_to_none=True)
     out3 = m(x[:2], t[:2], lt[:2], loss_prev=lp[:2], x_prev=xp[:2])
     out3.sum().backward()
-    assert torch.equal(m.decoder.ln_f.weight.grad, g2)
+    # (LayerNorm's dgamma / dbeta are accumulated with float atomics: equal up to the order of the additions)
+    assert torch.allclose(m.decoder.ln_f.weight.grad, g2, rtol=1e-4, atol=1e-5)
