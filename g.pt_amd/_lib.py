@@ -63,6 +63,7 @@ class Workspace(C.Structure):
 _PROTOS = {
     "gpt_abi_version": ([], i32),
     "gpt_gemm_nt": ([i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp], i32),
+    "gpt_gemm_nt_static": ([i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp], i32),
     "gpt_gemm_set_workspace": ([vp, C.c_size_t], i32),
     "gpt_gemm_tn": ([vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp], i32),
     "gpt_gemm_tn_grouped": ([i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp], i32),

@@ -28,6 +28,12 @@
 #include "gemm_common.h"
 #include <stdlib.h>
 
+#define CHECK_RC(call)          \
+  do {                          \
+    int _st = (call);           \
+    if (_st != 0) return _st;   \
+  } while (0)
+
 namespace gemmk {
 GemmProf g_prof;
 int gemm256_bf16(const GemmArgs<bf16_t>& g, int epi, int rt, hipStream_t s);  // gemm256.hip; rt = 8 | 7 (256- / 224-row tiles)
@@ -257,10 +263,40 @@ struct SplitWs {
   size_t bytes = 0;
 };
 SplitWs g_split_ws_dev[32];   // per device: the registration applies to the device current at the call
+thread_local SplitWs* g_ws_override = nullptr;   // set for the duration of a gpt_gemm_nt_static call (its static scratch)
 SplitWs& split_ws() {
+  if (g_ws_override) return *g_ws_override;
   int dev = 0;
   (void)hipGetDevice(&dev);
   return g_split_ws_dev[dev & 31];
+}
+
+// ---- the K-span scratch of gpt_gemm_nt_static: memory the library owns without ever allocating it ------------------------
+// A file-scope device array: every GPU the library runs on holds its own copy at its own address from the moment the code
+// object is loaded until the process ends.  The NAME `g_static_scratch` is a host-side stand-in, not a device address: host
+// code must only ever use the per-device pointer hipGetSymbolAddress returns (static_scratch_ptr below).
+constexpr size_t STATIC_SCRATCH_BYTES = (size_t)GPT_GEMM_STATIC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char g_static_scratch[STATIC_SCRATCH_BYTES];
+float* g_static_scratch_ptr[32] = {};
+
+// device pointer of the CURRENT device's copy (looked up once per device, with that device current)
+int static_scratch_ptr(float** out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) {
+    gpt_set_error("gpt_gemm_nt_static: no current device (or device index >= 32)");
+    return -1;
+  }
+  if (!g_static_scratch_ptr[dev]) {
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_static_scratch));
+    if (e != hipSuccess || !p) {
+      gpt_set_error("gpt_gemm_nt_static: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+      return -1;
+    }
+    g_static_scratch_ptr[dev] = (float*)p;
+  }
+  *out = g_static_scratch_ptr[dev];
+  return 0;
 }
 
 template <typename T, int EPI>
@@ -657,6 +693,23 @@ extern "C" int gpt_gemm_prof_collect(double* total_ms, double* total_flops, int*
   }
   *total_ms = ms; *total_flops = fl; *launches = g_prof.n;
   return 0;
+}
+
+extern "C" int gpt_gemm_nt_static(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                                  void* C, int64_t ldc, void* aux, int64_t ldaux, int M, int N, int K, int epilogue,
+                                  void* stream) {
+  // two K spans of partial tiles must fit, else the scratch could never be used for this problem: such problems belong to
+  // gpt_gemm_nt (at that size the single-pass kernels fill the chip anyway)
+  GPT_REQUIRE(M > 0 && N > 0 && (size_t)M * (size_t)N * sizeof(float) * 2 <= STATIC_SCRATCH_BYTES,
+              "gpt_gemm_nt_static: M x N = %d x %d exceeds the static scratch (%zu MiB holds two fp32 partial copies of at most "
+              "%zu output elements); use gpt_gemm_nt", M, N, STATIC_SCRATCH_BYTES >> 20, STATIC_SCRATCH_BYTES / 8);
+  SplitWs ws;
+  CHECK_RC(static_scratch_ptr(&ws.ptr));
+  ws.bytes = STATIC_SCRATCH_BYTES;
+  g_ws_override = &ws;          // pick_spans / dispatch see this device's static scratch instead of a registered workspace
+  const int rc = gpt_gemm_nt(dtype, A, lda, W, ldw, bias, C, ldc, aux, ldaux, M, N, K, epilogue, stream);
+  g_ws_override = nullptr;
+  return rc;
 }
 
 extern "C" int gpt_gemm_nt(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,

@@ -57,6 +57,20 @@ int gpt_gemm_nt(int dtype, const void* A, int64_t lda, const void* W, int64_t ld
  * 64 MiB covers the G.pt shapes.  (NULL, 0) unregisters.  No counterpart in the reference (an ATen/cuBLAS internal). */
 int gpt_gemm_set_workspace(void* ptr, size_t bytes);
 
+/* gpt_gemm_nt for callers that cannot allocate device memory or hand over a workspace (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same kernels and -
+ * against gpt_gemm_nt with a registered workspace of GPT_GEMM_STATIC_SCRATCH_BYTES - bit-identical results; the fp32 partial
+ * tiles of the K-span path go to a scratch array that is part of the library's code object (one copy per GPU, held until the
+ * process ends).  Calls no hipMalloc / hipFree or any allocating routine.  Limit: M * N * 8 <= GPT_GEMM_STATIC_SCRATCH_BYTES
+ * (larger problems are rejected with a negative status: they belong to gpt_gemm_nt, whose single-pass kernels need no
+ * scratch at that size).  All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (different
+ * streams, different threads) race on it; nothing in it has to be cleared between calls (every partial tile that is read
+ * was written by the same call). */
+#define GPT_GEMM_STATIC_SCRATCH_BYTES (64u << 20)
+int gpt_gemm_nt_static(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                       void* C, int64_t ldc, void* aux, int64_t ldaux, int M, int N, int K, int epilogue,
+                       void* stream);
+
 /* The residual Linear of a Block together with the LayerNorm that reads its result (Gpt/models/transformer.py:70-71:
  * x = x + attn(ln1(x)); then ln2(x) - and x = x + mlp(ln2(x)); then the next block's ln1 or ln_f, :311):
  *   x[M,N] (fp32, dense: ldx == N) = resid[M,N] (fp32, leading dim ldr; may be x itself) + A[M,K] . W[N,K]^T + bias
