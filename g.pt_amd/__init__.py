@@ -12,5 +12,6 @@ from .ddpm import (create_diffusion, GaussianDiffusion, SpacedDiffusion, Uniform
 from .dp import (is_main_proc, scaled_all_reduce, get_rank, get_world_size, synchronize, all_gather,  # noqa: F401
                  rank0_to_all)
 from . import permute  # noqa: F401
-from .evaluate import synth, create_thresholding_fn, mlp_test_losses, cnn_test_losses  # noqa: F401,E402
+from .evaluate import (synth, create_thresholding_fn, mlp_test_losses, cnn_test_losses, one_step_prompting,  # noqa: F401,E402
+                       recursive_prompting, aggregated_evolve, probe_G, batched_test_fn, batch_linspace, r_squared)
 from .data import CheckpointStore, write_flat_db  # noqa: F401,E402

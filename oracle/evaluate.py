@@ -55,3 +55,44 @@ def cnn_eval(nets, imgs, labels):
         losses.append(F.cross_entropy(logits, labels, reduction="none").mean())
         errs.append((logits.argmax(1) != labels).float().mean() * 100)
     return torch.stack(losses), torch.stack(errs)
+
+
+# ------------------------------------------------------------------------------------------ prompting chains
+def batch_linspace(start, end, steps):
+    """Gpt/vis.py:416-424, as written: one torch.linspace per row, from Python floats."""
+    return torch.stack([torch.linspace(s.item(), e.item(), steps=steps) for s, e in zip(start, end)], 0)
+
+
+def one_step_prompting(task_net, synth_fn, test_fn, best_prompt, minimize=True, dvo_steps=20, prompt_start_coeff=1.0):
+    """Gpt/vis.py:359-395 (regularly sampled prompts).  synth_fn(desired, current, nets) -> evolved nets;
+    test_fn(nets [N, D]) -> losses [N] (the per-net batch_test_fn loop, vis.py:398-413, folded into test_fn)."""
+    n = task_net.size(0)
+    base = test_fn(task_net).float()
+    desired = batch_linspace(torch.full((n,), float(best_prompt)), base * prompt_start_coeff, dvo_steps)
+    if not minimize:
+        desired = desired.flip(1,)
+    evolved = synth_fn(desired.flatten(), base.repeat_interleave(dvo_steps, dim=0), task_net.repeat_interleave(dvo_steps, dim=0))
+    observed = torch.cat([base.view(n, 1), test_fn(evolved).float().view(n, dvo_steps)], 1)
+    return desired, observed, evolved
+
+
+def recursive_prompting(task_net, synth_fn, test_fn, recursive_prompt, best_prompt=None, minimize=True, interp_alg="zero",
+                        max_steps=2, step_divider=5):
+    """Gpt/vis.py:325-356."""
+    n = task_net.size(0)
+    cur_loss, cur_net = test_fn(task_net).float(), task_net
+    desired, observed, nets = [], [cur_loss], []
+    sign = -1 if minimize else 1
+    for _ in range(max_steps):
+        if interp_alg == "zero":
+            want = torch.full((n,), float(recursive_prompt))
+        elif interp_alg == "step":
+            want = cur_loss + sign * (best_prompt / float(step_divider))
+        else:
+            raise NotImplementedError
+        desired.append(want)
+        cur_net = synth_fn(want, cur_loss, cur_net)
+        cur_loss = test_fn(cur_net).float()
+        observed.append(cur_loss)
+        nets.append(cur_net)
+    return torch.stack(desired, 1), torch.stack(observed, 1), nets

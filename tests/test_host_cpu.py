@@ -216,3 +216,46 @@ sys.meta_path.append(_Stub())          # after the real finders: only what is no
         assert "Gpt." not in res.stderr.splitlines()[-1] or "No module named 'Gpt" not in res.stderr, res.stderr[-2000:]
         pytest.skip("a reference module needs a dependency the stubs do not cover: " + res.stderr.splitlines()[-1])
     assert "/root/reference/Gpt/utils.py" in res.stdout
+
+
+def test_prompting_chain_host_helpers():
+    """batch_linspace / r_squared / batch_test_fn of the evaluation chains (Gpt/vis.py:255-266, 398-424) against the oracle's
+    as-written restatement; a chain run on CPU tensors with stand-in synth / test functions checks the bookkeeping
+    (repeat_interleave order, shapes, the feedback of recursive prompting) without any kernel."""
+    from gpt_amd import evaluate as ev
+    from oracle import evaluate as oe
+    g = torch.Generator().manual_seed(0)
+    a, b = torch.rand(16, generator=g) * 90, torch.rand(16, generator=g) * 3
+    for steps in (1, 2, 3, 20, 21):
+        x, y = ev.batch_linspace(a, b, steps), oe.batch_linspace(a, b, steps)
+        assert x.shape == y.shape == (16, steps)
+        assert float((x - y).abs().max()) <= 2 * 2.0 ** -23 * 90
+        assert torch.equal(x[:, 0], a) and (steps == 1 or torch.equal(x[:, -1], b))
+    p, t = torch.rand(4, 7, generator=g), torch.rand(4, 7, generator=g)
+    avg = t.mean(1, keepdim=True)
+    assert abs(ev.r_squared(p, t) - float((1 - (t - p).pow(2).sum(1) / ((t - avg).pow(2).sum(1) + 1e-8)).mean())) < 1e-7
+    # stand-ins: "loss" of a net = its mean; synth moves every net a fixed fraction of the way to the prompted loss
+    test_fn = lambda nets: nets.mean(1)                                                  # noqa: E731
+    test_fn.batched = True
+    per_net = lambda net: float(net.mean())                                              # noqa: E731  (the reference's form)
+    synth = lambda diffusion, G, want, cur, nets: nets + 0.5 * (want - cur).view(-1, 1)   # noqa: E731
+    nets = torch.rand(3, 5, generator=g) + 2.0
+    meta = dict(minimize=True, best_prompt=0.0, recursive_prompt=0.5)
+    d, o = ev.one_step_prompting(nets, synth, None, None, test_fn, meta, dvo_steps=4)
+    d2, o2, _ = oe.one_step_prompting(nets, lambda w, c, n: synth(None, None, w, c, n), test_fn, 0.0, dvo_steps=4)
+    assert d.shape == (3, 4) and o.shape == (3, 5) and torch.allclose(d, d2) and torch.allclose(o, o2)
+    d3, o3 = ev.one_step_prompting(nets, synth, None, None, per_net, meta, dvo_steps=4)     # per-net test_fn: same numbers
+    assert torch.allclose(o3, o) and torch.allclose(d3, d)
+    assert torch.allclose(o[:, 1:], 0.5 * (d + o[:, :1]), atol=1e-6)                       # evolved loss = halfway to the prompt
+    r, ro = ev.recursive_prompting(nets, synth, None, None, test_fn, meta, max_steps=3)
+    r2, ro2, _ = oe.recursive_prompting(nets, lambda w, c, n: synth(None, None, w, c, n), test_fn, 0.5, max_steps=3)
+    assert r.shape == (3, 3) and ro.shape == (3, 4) and torch.allclose(r, r2) and torch.allclose(ro, ro2)
+    assert torch.allclose(ro[:, 2] - 0.5, 0.25 * (ro[:, 0] - 0.5), atol=1e-6)              # each loop halves the gap: feedback works
+    qa, ra = ev.aggregated_evolve(ev.one_step_prompting, nets, 2, synth, None, None, test_fn, meta, dvo_steps=4)
+    assert torch.allclose(qa, d) and torch.allclose(ra, o)                                 # mini-batches of 2 + 1 nets
+    dd, oo = ev.probe_G(ev.recursive_prompting, nets, 2, synth, None, None, test_fn, meta, ["zero", "step"], max_steps=2)
+    assert dd.shape == (2, 3, 2) and oo.shape == (2, 3, 3)
+    # explicitly given prompts (vis.py:377-381): row window by tasknet_index, first column = the starting loss
+    given = torch.rand(5, 6, generator=g)
+    d4, o4 = ev.one_step_prompting(nets[:2], synth, None, None, test_fn, meta, tasknet_index=1, dvo_steps=4, desired_losses=given)
+    assert torch.equal(d4, given[1:3, :4]) and o4.shape == (2, 5)
