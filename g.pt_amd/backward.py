@@ -13,7 +13,14 @@ from . import _lib as L
 
 
 class GradArena:
-    """Flat fp32 gradient buffer + the C descriptor that points the kernels at its slices."""
+    """Flat fp32 gradient buffer + the C descriptor that points the kernels at its slices.
+
+    Two regions.  S ("sharded"): the Linear weights of the blocks, layer by layer (query | key | value back to back = the fused
+    [3d, d] operand, proj, mlp.0, mlp.2), then the decoder Linears - 99 % of the elements, every tensor a multiple of 64
+    elements (n_embd % 64 == 0), so any run of whole tensors splits evenly over 1 / 2 / 4 / 8 / 16 ranks: the region the
+    data-parallel step reduce-scatters, updates 1/world of, and all-gathers as bf16 operands (trainstep.py).  R ("replicated"):
+    biases, LayerNorm parameters, pos_emb and the ragged encoder Linears (K-padded operand layout) - all-reduced and updated on
+    every rank."""
 
     def __init__(self, model, device):
         dec = model.decoder
@@ -27,38 +34,47 @@ class GradArena:
             off += (numel + 7) // 8 * 8       # every slice 32-byte aligned (16 bytes in a bf16 copy of the arena)
             return self.slices[name][0]
 
-        self.layer_off = []
+        self.layer_off = [dict() for _ in range(Lr)]
+        # ---- region S
+        self.s_layer_start = []
         for l in range(Lr):
             p = f"decoder.blocks.{l}."
-            lo = {}
-            # fused [3d, d] weight / [3d] bias gradients: query | key | value back to back (no padding between them)
+            lo = self.layer_off[l]
+            self.s_layer_start.append(off)
+            # fused [3d, d] weight gradient: query | key | value back to back (no padding between them)
             lo["g_wqkv"] = off
             for nm in ("query", "key", "value"):
                 self.slices[p + f"attn.{nm}.weight"] = (off, d * d)
                 off += d * d
-            lo["g_bqkv"] = off
+            off = (off + 7) // 8 * 8
+            lo["g_wproj"] = take(p + "attn.proj.weight", d * d)
+            lo["g_w1"] = take(p + "mlp.0.weight", 4 * d * d)
+            lo["g_w2"] = take(p + "mlp.2.weight", 4 * d * d)
+        self.s_dec_start = off
+        self.dec_off = [take(f"decoder.output_parameter_projections.{j}.0.weight", n * d)
+                        for j, n in enumerate(dec.output_splits)]
+        self.s_end = self.r_start = off
+        # ---- region R
+        for l in range(Lr):
+            p = f"decoder.blocks.{l}."
+            lo = self.layer_off[l]
+            lo["g_bqkv"] = off                # [3d] bias gradient: query | key | value back to back
             for nm in ("query", "key", "value"):
                 self.slices[p + f"attn.{nm}.bias"] = (off, d)
                 off += d
             off = (off + 7) // 8 * 8
-            lo["g_wproj"] = take(p + "attn.proj.weight", d * d)
             lo["g_bproj"] = take(p + "attn.proj.bias", d)
-            lo["g_w1"] = take(p + "mlp.0.weight", 4 * d * d)
             lo["g_b1"] = take(p + "mlp.0.bias", 4 * d)
-            lo["g_w2"] = take(p + "mlp.2.weight", 4 * d * d)
             lo["g_b2"] = take(p + "mlp.2.bias", d)
             for ln in ("ln1", "ln2"):
                 lo[f"g_{ln}_w"] = take(p + ln + ".weight", d)
                 lo[f"g_{ln}_b"] = take(p + ln + ".bias", d)
-            self.layer_off.append(lo)
         self.glob = {"g_pos_emb": take("decoder.pos_emb", dec.block_size * d)}
         for ln, key in (("ln_in", "g_ln_in"), ("ln_f", "g_ln_f")):
             self.glob[key + "_w"] = take(f"decoder.{ln}.weight", d)
             self.glob[key + "_b"] = take(f"decoder.{ln}.bias", d)
         self.enc_off = [take(f"decoder.input_parameter_projections.{i}.0.weight", d * k)
                         for i, k in enumerate(dec.input_splits)]
-        self.dec_off = [take(f"decoder.output_parameter_projections.{j}.0.weight", n * d)
-                        for j, n in enumerate(dec.output_splits)]
         self.numel = off
         self.device = device
         self.names = [n for n, _ in model.named_parameters()]

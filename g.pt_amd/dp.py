@@ -193,6 +193,43 @@ def all_reduce_ranges(flat, ranges, async_op=True):
     return [dist.all_reduce(flat[lo:hi], async_op=async_op) for lo, hi in ranges]
 
 
+def _host_staged(t):
+    """True for a device tensor on a process group without a device transport (gloo: the rehearsal of the multi-GPU path
+    with several ranks on one GPU): the collective then runs on a host copy, synchronously."""
+    return t.is_cuda and dist.get_backend() != "nccl"
+
+
+def reduce_scatter_into(out, inp, async_op=True):
+    """out[c] = SUM over ranks of inp[rank * c : (rank + 1) * c]  (inp: world * c elements; no 1/world scale).  The first half
+    of a ring all-reduce: each rank receives only the 1/world of the sum it is going to update.  Returns a work handle or None."""
+    if not exchanging():
+        out.copy_(inp[:out.numel()])
+        return None
+    assert inp.numel() == out.numel() * get_world_size()
+    if _host_staged(inp):
+        h_in, h_out = inp.cpu(), torch.empty(out.shape, dtype=out.dtype)
+        dist.reduce_scatter_tensor(h_out, h_in)
+        out.copy_(h_out)
+        return None
+    return dist.reduce_scatter_tensor(out, inp, async_op=async_op)
+
+
+def all_gather_into(full, own, async_op=True):
+    """full[rank * c : (rank + 1) * c] = every rank's `own` (c elements).  `own` may be the matching slice of `full` itself
+    (in place: nothing is copied locally).  The second half of a ring all-reduce.  Returns a work handle or None."""
+    if not exchanging():
+        if own.data_ptr() != full.data_ptr():
+            full[:own.numel()].copy_(own)
+        return None
+    assert full.numel() == own.numel() * get_world_size()
+    if _host_staged(full):
+        h_own, h_full = own.cpu(), torch.empty(full.shape, dtype=full.dtype)
+        dist.all_gather_into_tensor(h_full, h_own)
+        full.copy_(h_full)
+        return None
+    return dist.all_gather_into_tensor(full, own, async_op=async_op)
+
+
 def wait_all(handles):
     for h in handles:
         if h is not None:

@@ -64,21 +64,40 @@ class FlatState:
         return self.arena.views(buf, model)
 
     # ---- packed operand copies
+    def segment_rows(self, code):
+        """[(start, count, decay, k, ld, packed_off)] of every parameter in arena order (gpt_opt_segment_t, include/gpt_hip.h)."""
+        rows = []
+        enc = {n: i for i, n in enumerate(self.enc_names)}
+        for name, (o, n) in sorted(self.arena.slices.items(), key=lambda kv: kv[1][0]):
+            k, ld, packed_off = 1, 1, -1
+            if name in enc:
+                i = enc[name]
+                k, ld, packed_off = self.enc_k[i], _round_up(self.enc_k[i], 32), self.enc_off[i] - self._base(code)
+            elif code == L.BF16 and self.decay[name]:
+                packed_off = o
+            rows.append((o, n, self.decay[name], k, ld, packed_off))
+        return rows
+
+    def segment_table(self, code, lo, hi):
+        """Device table of the segments that overlap arena elements [lo, hi), with their starts relative to `lo`: the table of
+        an optimizer pass over params + lo ... (a data-parallel rank's shard, trainstep.py).  packed_off stays absolute."""
+        rows = self.segment_rows(code)
+        ends = [r[0] for r in rows[1:]] + [self.numel]
+        sel = [r for r, e in zip(rows, ends) if r[0] < hi and e > lo]
+        arr = (L.OptSegment * len(sel))()
+        for s, (o, n, decay, k, ld, packed_off) in zip(arr, sel):
+            s.start, s.count, s.decay, s.k, s.ld, s.packed_off = o - lo, n, decay, k, ld, packed_off
+            # a partly covered segment is only safe for plain copies (the K-padded layout indexes from the segment's start)
+            assert k == ld or (o >= lo and o + n <= hi) or packed_off < 0
+            if packed_off >= 0 and k == ld:
+                s.packed_off = packed_off        # element e of the pass maps to packed_off + (e - start)
+        host = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+        return torch.from_numpy(host).to(self.device), len(sel)
+
     def segments(self, code):
         seg = self._segments.get(code)
         if seg is None:
-            order = sorted(self.arena.slices.items(), key=lambda kv: kv[1][0])
-            arr = (L.OptSegment * len(order))()
-            enc = {n: i for i, n in enumerate(self.enc_names)}
-            for s, (name, (o, n)) in zip(arr, order):
-                s.start, s.count, s.decay, s.k, s.ld, s.packed_off = o, n, self.decay[name], 1, 1, -1
-                if name in enc:
-                    i = enc[name]
-                    s.k, s.ld, s.packed_off = self.enc_k[i], _round_up(self.enc_k[i], 32), self.enc_off[i] - self._base(code)
-                elif code == L.BF16 and self.decay[name]:
-                    s.packed_off = o
-            host = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
-            seg = self._segments[code] = (torch.from_numpy(host).to(self.device), len(order))
+            seg = self._segments[code] = self.segment_table(code, 0, self.numel)
         return seg
 
     def _base(self, code):

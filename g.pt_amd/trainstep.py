@@ -52,7 +52,7 @@ class TrainStep:
     configure_optimizers, accumulate) over the same gradient arena - the cross-check of the fused pass."""
 
     def __init__(self, model, diffusion, lr=4e-4, wd=0.1, betas=(0.9, 0.999), eps=1e-8, grad_clip=0.75, ema_decay=0.9999,
-                 use_ema=True, bucket_layers=None, fused=True, overlap=True):
+                 use_ema=True, bucket_layers=None, fused=True, overlap=True, shard=None, grad_payload=None):
         self.model, self.diffusion = model, diffusion
         self.device = model.decoder.pos_emb.device
         self.lr, self.wd, self.betas, self.eps = lr, wd, betas, eps
@@ -77,9 +77,17 @@ class TrainStep:
         self.grads = self.flat.like()
         for p, g in zip(model.parameters(), self.flat.views(self.grads, model)):
             p.grad = g
-        if fused:
+        # data-parallel optimizer sharding (fused step only; GPT_DP_SHARD=0 keeps every rank's full update)
+        if shard is None:
+            shard = os.environ.get("GPT_DP_SHARD", "1") != "0"
+        self.shard = bool(shard and fused and dp.exchanging())
+        self.grad_payload = grad_payload or os.environ.get("GPT_DP_GRAD_PAYLOAD", "fp32")
+        assert self.grad_payload in ("fp32", "bf16")
+        self.rank = dp.get_rank()
+        if fused and not self.shard:
             self.exp_avg, self.exp_avg_sq = self.flat.like(), self.flat.like()
-            self.norm_scratch = torch.zeros(1024 + 4, dtype=torch.float32, device=self.device)
+        if fused:
+            self.norm_scratch = torch.zeros(1024 + 8, dtype=torch.float32, device=self.device)
             self.optimizer = None
         else:
             self.optimizer = model.configure_optimizers(lr=lr, wd=wd, betas=betas)
@@ -89,22 +97,90 @@ class TrainStep:
             bucket_layers = int(os.environ.get("GPT_DP_BUCKET_LAYERS", "2"))
         assert bucket_layers >= 1
         self.buckets = self._make_buckets(bucket_layers)
+        if self.shard:
+            self._init_shards()
         self.tmap = torch.tensor(diffusion._timestep_map(), device=self.device, dtype=torch.long)
         self.iteration = 0
 
     def _make_buckets(self, bucket_layers):
-        """Contiguous arena ranges in the order the backward finishes them: layer groups from the last to the first,
-        then the tensors outside the blocks (pos_emb, ln_in / ln_f, encoder and decoder Linears)."""
-        Lr = self.model.decoder.n_layer
-        starts = [self.arena.layer_off[l]["g_wqkv"] for l in range(Lr)] + [self.arena.glob["g_pos_emb"]]
-        out = []                           # (lo, hi, stage_end): complete once the backward stages < stage_end ran
+        """Contiguous arena ranges (lo, hi, stage_end, region), in the order the backward finishes them (complete once the
+        backward stages < stage_end ran): the decoder Linears, layer groups of weights from the last block to the first
+        (region S of the arena), then region R (biases, LayerNorm, pos_emb, encoder Linears)."""
+        ar, Lr = self.arena, self.model.decoder.n_layer
+        starts = list(ar.s_layer_start) + [ar.s_dec_start]
+        out = [(ar.s_dec_start, ar.s_end, 1, "S")]
         hi = Lr
         while hi > 0:
             lo = max(0, hi - bucket_layers)
-            out.append((starts[lo], starts[hi], Lr - lo + 1))
+            out.append((starts[lo], starts[hi], Lr - lo + 1, "S"))
             hi = lo
-        out.append((starts[Lr], self.arena.numel, Lr + 2))
+        out.append((ar.r_start, ar.numel, Lr + 2, "R"))
         return out
+
+    # ---- data-parallel sharding of the optimizer (ZeRO-1 style) ------------------------------------------------------------
+    # Replicated step (what DistributedDataParallel + a per-rank optimizer do in the reference, main.py:229-240, 66-74): every
+    # rank all-reduces all gradients (ring: reduce-scatter + all-gather of 4 P bytes) and then runs the SAME optimizer pass
+    # over all P parameters (42 bytes of HBM traffic per parameter: 2.85 ms of a 14 ms step at B = 128, on every rank).
+    # Sharded step: for every S bucket the fp32 gradient sum is reduce-scattered (rank r receives chunk r), the fused
+    # clip + AdamW + EMA pass updates that 1/world of the parameters (moments and EMA exist for the own shard only) and writes
+    # their bf16 operand copies, and the OPERANDS are all-gathered (bf16: half the bytes of the all-reduce's second half;
+    # fp32 compute mode gathers the fp32 parameters).  Region R (1 % of the elements) stays all-reduced and replicated.
+    # fp32 parameters (and the EMA) outside the own shard are refreshed lazily: sync_params() / sync_ema(), which the
+    # state_dict() hooks call, so checkpoints are always whole.
+    def _init_shards(self):
+        w, r = self.world, self.rank
+        self.s_chunks = []                   # per S bucket: (lo, hi, c, own_lo, g_off)
+        g_off = 0
+        for lo, hi, _, region in self.buckets:
+            if region != "S":
+                continue
+            assert (hi - lo) % (4 * w) == 0, "S buckets hold whole Linear weights (multiples of 64 elements): world <= 16"
+            c = (hi - lo) // w
+            self.s_chunks.append((lo, hi, c, lo + r * c, g_off))
+            g_off += c
+        self.n_own, self.n_rep = g_off, self.arena.numel - self.arena.r_start
+        dev = self.device
+        self.gshard = torch.zeros(self.n_own, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(self.n_own + self.n_rep, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(self.n_own + self.n_rep, dtype=torch.float32, device=dev)
+        self.seg_tables = [self.flat.segment_table(self.code, own, own + c) for _, _, c, own, _ in self.s_chunks]
+        self.seg_rep = self.flat.segment_table(self.code, self.arena.r_start, self.arena.numel)
+        if self.grad_payload == "bf16":      # bf16 gradient payload: staging copies of the S region and of the own shard
+            self.g16 = torch.zeros(self.arena.s_end, dtype=torch.bfloat16, device=dev)
+            self.gshard16 = torch.zeros(self.n_own, dtype=torch.bfloat16, device=dev)
+        self._params_stale = self._ema_stale = False
+        self.model.register_state_dict_pre_hook(lambda *a, **k: self.sync_params())
+        if self.ema is not None:
+            self.ema.register_state_dict_pre_hook(lambda *a, **k: self.sync_ema())
+
+    def _launch_bucket(self, lo, hi, region):
+        """Puts the gradient exchange of one finished bucket in flight."""
+        if not self.shard or region == "R":
+            self._handles.extend(dp.all_reduce_ranges(self.grads, [(lo, hi)]))
+            return
+        _, _, c, _, g_off = next(ch for ch in self.s_chunks if ch[0] == lo)
+        if self.grad_payload == "bf16":
+            L.check(L.lib().gpt_f32_to_bf16(L.ptr(self.grads[lo:hi]), L.ptr(self.g16[lo:hi]), hi - lo, L.stream()), "gpt_f32_to_bf16")
+            self._handles.append(dp.reduce_scatter_into(self.gshard16[g_off:g_off + c], self.g16[lo:hi]))
+        else:
+            self._handles.append(dp.reduce_scatter_into(self.gshard[g_off:g_off + c], self.grads[lo:hi]))
+
+    def _gather(self, buf, stale_attr):
+        """All-gathers every S bucket of an arena-shaped buffer in place from the ranks' own chunks."""
+        hs = [dp.all_gather_into(buf[lo:hi], buf[own:own + c]) for lo, hi, c, own, _ in self.s_chunks]
+        dp.wait_all(hs)
+        setattr(self, stale_attr, False)
+
+    @torch.no_grad()
+    def sync_params(self):
+        """fp32 parameters of the other ranks' shards (bf16 compute mode gathers only the bf16 operands per step)."""
+        if self.shard and self._params_stale:
+            self._gather(self.flat.params, "_params_stale")
+
+    @torch.no_grad()
+    def sync_ema(self):
+        if self.shard and self._ema_stale and self.flat_ema is not None:
+            self._gather(self.flat_ema.params, "_ema_stale")
 
     def set_lr(self, lr):
         self.lr = lr
@@ -142,8 +218,8 @@ class TrainStep:
         self._handles = []
         schedule = None
         if dp.exchanging() and self.overlap:
-            schedule = [(stage_end, (lambda lo=lo, hi=hi: self._handles.extend(dp.all_reduce_ranges(self.grads, [(lo, hi)]))))
-                        for lo, hi, stage_end in self.buckets]
+            schedule = [(stage_end, (lambda lo=lo, hi=hi, region=region: self._launch_bucket(lo, hi, region)))
+                        for lo, hi, stage_end, region in self.buckets]
         if self._t_ready is not None:
             torch.cuda.current_stream().wait_event(self._t_ready)
             self._t_ready = None
@@ -155,9 +231,12 @@ class TrainStep:
         """Completes the gradient exchange (launches it here when not overlapped); the 1/world scale is folded into the
         optimizer pass."""
         if dp.exchanging() and not self.overlap:
-            self._handles = dp.all_reduce_ranges(self.grads, [(lo, hi) for lo, hi, _ in self.buckets])
+            for lo, hi, _, region in self.buckets:
+                self._launch_bucket(lo, hi, region)
         dp.wait_all(self._handles)
         self._handles = []
+        if self.shard and self.grad_payload == "bf16":
+            L.check(L.lib().gpt_bf16_to_f32(L.ptr(self.gshard16), L.ptr(self.gshard), self.n_own, L.stream()), "gpt_bf16_to_f32")
 
     @torch.no_grad()
     def update(self):
@@ -176,16 +255,48 @@ class TrainStep:
             return
         lib, st = L.lib(), L.stream()
         n = self.flat.numel
-        if self.grad_clip > 0:
-            L.check(lib.gpt_grad_sumsq(L.ptr(self.grads), n, L.ptr(self.norm_scratch), L.ptr(self.grad_norm_sq), st),
-                    "gpt_grad_sumsq")
-        seg, n_seg = self.flat.segments(self.code)
         packed = self.flat.packed(self.code)
-        L.check(lib.gpt_adamw_ema_step(
-            L.ptr(self.flat.params), L.ptr(self.grads), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
-            L.ptr(self.flat_ema.params) if self.flat_ema is not None else None, L.ptr(packed), self.code, L.ptr(seg), n_seg,
-            n, L.ptr(self.grad_norm_sq), float(self.grad_clip), 1.0 / self.world, self.lr, self.betas[0], self.betas[1],
-            self.eps, self.wd, self.iteration, self.ema_decay, 1, st), "gpt_adamw_ema_step")
+        ema = self.flat_ema.params if self.flat_ema is not None else None
+
+        def adamw(lo, count, grads, m_off, seg, n_seg, zero_grad):
+            """The fused pass over arena elements [lo, lo + count); moments at m_off of the moment buffers."""
+            L.check(lib.gpt_adamw_ema_step(
+                L.ptr(self.flat.params[lo:]), L.ptr(grads), L.ptr(self.exp_avg[m_off:]), L.ptr(self.exp_avg_sq[m_off:]),
+                L.ptr(ema[lo:]) if ema is not None else None, L.ptr(packed), self.code, L.ptr(seg), n_seg, count,
+                L.ptr(self.grad_norm_sq), float(self.grad_clip), 1.0 / self.world, self.lr, self.betas[0], self.betas[1],
+                self.eps, self.wd, self.iteration, self.ema_decay, zero_grad, st), "gpt_adamw_ema_step")
+
+        if not self.shard:
+            if self.grad_clip > 0:
+                L.check(lib.gpt_grad_sumsq(L.ptr(self.grads), n, L.ptr(self.norm_scratch), L.ptr(self.grad_norm_sq), st),
+                        "gpt_grad_sumsq")
+            seg, n_seg = self.flat.segments(self.code)
+            adamw(0, n, self.grads, 0, seg, n_seg, 1)
+        else:
+            r0 = self.arena.r_start
+            if self.grad_clip > 0:
+                # |g|^2 = the ranks' own S chunks summed over the ranks + region R (identical on every rank after its all-reduce)
+                part = self.norm_scratch[1026:1028]
+                L.check(lib.gpt_grad_sumsq(L.ptr(self.gshard), self.n_own, L.ptr(self.norm_scratch), L.ptr(part[0:1]), st), "gpt_grad_sumsq")
+                if dp._host_staged(part):
+                    host = part[0:1].cpu()
+                    dist.all_reduce(host)
+                    part[0:1].copy_(host)
+                else:
+                    dist.all_reduce(part[0:1])
+                L.check(lib.gpt_grad_sumsq(L.ptr(self.grads[r0:]), self.n_rep, L.ptr(self.norm_scratch), L.ptr(part[1:2]), st), "gpt_grad_sumsq")
+                torch.add(part[0:1], part[1:2], out=self.grad_norm_sq)
+            for (lo, hi, c, own, g_off), (seg, n_seg) in zip(self.s_chunks, self.seg_tables):
+                adamw(own, c, self.gshard[g_off:], g_off, seg, n_seg, 0)
+            adamw(r0, self.n_rep, self.grads[r0:], self.n_own, self.seg_rep[0], self.seg_rep[1], 0)
+            self.grads.zero_()
+            # the updated operands of every rank's shard: bf16 copies in bf16 compute mode (half the bytes), else the fp32 parameters
+            if self.code == L.BF16:
+                self._gather(packed, "_params_stale")
+                self._params_stale = True      # the fp32 parameters of the other shards follow on demand (sync_params)
+            else:
+                self._gather(self.flat.params, "_params_stale")
+            self._ema_stale = ema is not None
         # the step wrote the parameters and this engine's packed operands together, behind torch's back (the EMA copy's own
         # engines re-derive their operands on every use: denoiser.py _Engine.refresh)
         self.eng.touched()

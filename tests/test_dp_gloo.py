@@ -120,6 +120,20 @@ def _body_grads(rank):
     h = dp.all_reduce_ranges(flat, [(6, 10), (2, 6), (0, 2)])
     dp.wait_all(h)
     assert torch.equal(flat, torch.arange(10.0) * 3)
+    # the two halves of that exchange on their own (the sharded optimizer step): rank r receives the sum of chunk r, updates it,
+    # and the chunks are gathered back in place
+    arena = torch.arange(12.0) * (rank + 1)
+    own = torch.zeros(3)
+    dp.wait_all([dp.reduce_scatter_into(own, arena[2:8])])
+    assert torch.equal(own, (torch.arange(12.0) * 3)[2 + 3 * rank: 5 + 3 * rank])
+    arena[2 + 3 * rank: 5 + 3 * rank] = own * 10
+    dp.wait_all([dp.all_gather_into(arena[2:8], arena[2 + 3 * rank: 5 + 3 * rank])])
+    assert torch.equal(arena[2:8], torch.arange(12.0)[2:8] * 30)
+    assert torch.equal(arena[:2], torch.arange(2.0) * (rank + 1)) and torch.equal(arena[8:], torch.arange(12.0)[8:] * (rank + 1))
+    half = torch.tensor([1.0, 2.0, 3.0, 4.0]).bfloat16() * (rank + 1)
+    got = torch.zeros(2, dtype=torch.bfloat16)
+    dp.wait_all([dp.reduce_scatter_into(got, half)])
+    assert got.float().tolist() == ([3.0, 6.0] if rank == 0 else [9.0, 12.0])
 
 
 # ---------------------------------------------------------------------------------------------- tests
@@ -143,4 +157,7 @@ def test_single_process_short_circuits():
     assert dp.all_gather(x) is x and dp.gather_rows(x, 3) is x
     assert torch.equal(dp.rank0_to_all(x), x[0])
     assert dp.all_reduce_ranges(x.view(-1), [(0, 6)]) == []
+    out = torch.zeros(6)
+    assert dp.reduce_scatter_into(out, x.view(-1)) is None and torch.equal(out, x.view(-1))
+    assert dp.all_gather_into(out, out) is None
     assert dp.shard_rows(10, rank=1, world=4) == (3, 6) and dp.shard_rows(10, rank=3, world=4) == (9, 10)

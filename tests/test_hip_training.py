@@ -242,8 +242,10 @@ def test_fused_step_matches_torch_optimizer_over_steps():
 
 
 # ---------------------------------------------------------------------------------------------- data parallel
-def _ddp_rank(rank, world, port, out_path):
-    """One rank of a 2-process data-parallel step; both ranks use GPU 0 (the box has one), so the exchange runs on gloo."""
+def _ddp_rank(rank, world, port, out_path, mode="replicated", dtype="fp32"):
+    """One rank of a 2-process data-parallel step; both ranks use GPU 0 (the box has one), so the exchange runs on gloo.
+    mode: 'replicated' (all-reduce, every rank updates everything) | 'sharded' (reduce-scatter, 1/world AdamW, all-gather of the
+    operands) | 'sharded_bf16' (the same with the bf16 gradient payload)."""
     import faulthandler
     import os
     import torch.distributed as dist
@@ -252,16 +254,31 @@ def _ddp_rank(rank, world, port, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from gpt_amd.trainstep import TrainStep
-        m, plan, sd = build("mnist_small", "fp32", seed=3 + rank)       # different weights: rank 0's must win the broadcast
+        m, plan, sd = build("mnist_small", dtype, seed=3 + rank)       # different weights: rank 0's must win the broadcast
         m.train()
         diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
-        ts = TrainStep(m, diff, lr=1e-3, wd=0.1, grad_clip=0.75, bucket_layers=1)
+        ts = TrainStep(m, diff, lr=1e-3, wd=0.1, grad_clip=0.75, bucket_layers=1, shard=mode != "replicated",
+                       grad_payload="bf16" if mode == "sharded_bf16" else "fp32")
+        assert ts.shard == (mode != "replicated")
         for i in range(2):
             batch = _ddp_batch(i)
             sl = slice(rank * 4, rank * 4 + 4)
             ts.step(*(v[sl] for v in batch))
-        if rank == 0:
-            torch.save({k: p.detach().cpu() for k, p in m.named_parameters()}, out_path)
+        if ts.shard:
+            own = ts.s_chunks[0]
+            assert ts.exp_avg.numel() == ts.n_own + ts.n_rep and ts.n_own == ts.arena.s_end // world    # moments: own shard + region R
+            if dtype == "bf16":
+                assert ts._params_stale                                                # fp32 copies of the other shard: on demand
+        # state_dict() (what a checkpoint writes, main.py:92-97) must be whole on every rank: its hook gathers the fp32 shards
+        sd_now = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        ema_now = {k: v.detach().cpu() for k, v in ts.ema.state_dict().items()}
+        # ... and what the next forward reads (packed operands) must be the updated weights on every rank
+        with torch.no_grad():
+            x, tt, lt2, lp2, xp2 = (v.to(DEV) for v in make_inputs("mnist_small", B=4, seed=5))
+            out = m(x, tt, lt2, loss_prev=lp2, x_prev=xp2).cpu()
+        torch.save({"params": {k: v for k, v in sd_now.items() if k != "scalar_embedder.frequencies"},
+                    "ema": {k: v for k, v in ema_now.items() if k != "scalar_embedder.frequencies"}, "out": out},
+                   out_path + f".{rank}")
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -276,17 +293,20 @@ def _ddp_batch(i):
     return xp, x1, lp, lt, t, torch.ones(8, device=DEV), noise
 
 
-def test_two_rank_step_equals_full_batch(tmp_path):
-    """2 ranks x 4 rows with the staged, overlapped gradient exchange == 1 process x 8 rows (two steps, fp32)."""
+@pytest.mark.parametrize("mode,dtype", [("replicated", "fp32"), ("sharded", "fp32"), ("sharded", "bf16"), ("sharded_bf16", "bf16")])
+def test_two_rank_step_equals_full_batch(tmp_path, mode, dtype):
+    """2 ranks x 4 rows with the staged, overlapped gradient exchange == 1 process x 8 rows (two steps): the replicated step
+    (all-reduce), the sharded step (reduce-scatter -> AdamW on 1/world -> all-gather of the operands; fp32 and bf16 compute)
+    and the sharded step with the bf16 gradient payload.  Parameters, EMA and the next forward's output, on BOTH ranks."""
     import socket
     import torch.multiprocessing as mp
     from gpt_amd.trainstep import TrainStep
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    out_path = str(tmp_path / "rank0.pt")
+    out_path = str(tmp_path / "rank")
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_ddp_rank, args=(r, 2, port, out_path)) for r in range(2)]
+    procs = [ctx.Process(target=_ddp_rank, args=(r, 2, port, out_path, mode, dtype)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -294,17 +314,34 @@ def test_two_rank_step_equals_full_batch(tmp_path):
         if p.exitcode is None:
             p.kill()
         assert p.exitcode == 0
-    got = torch.load(out_path, weights_only=True)
-    m, plan, sd = build("mnist_small", "fp32", seed=3)
+    m, plan, sd = build("mnist_small", dtype, seed=3)
     m.train()
     diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
     ts = TrainStep(m, diff, lr=1e-3, wd=0.1, grad_clip=0.75)
     for i in range(2):
         ts.step(*_ddp_batch(i))
-    for k, p in m.named_parameters():
-        if k.endswith("attn.key.bias"):
-            continue
-        assert float((p.detach().cpu() - got[k]).abs().max()) < 5e-5 * max(1.0, float(got[k].abs().max())), k
+    with torch.no_grad():
+        x, tt, lt2, lp2, xp2 = (v.to(DEV) for v in make_inputs("mnist_small", B=4, seed=5))
+        want_out = m(x, tt, lt2, loss_prev=lp2, x_prev=xp2).cpu()
+    # fp32 compute: the two paths differ by summation order only.  bf16 compute: the gradients of 2 x 4 rows and of 8 rows see
+    # differently rounded operands; a bf16 gradient payload rounds the summed gradients once more (Adam's first steps are
+    # sign-like, so single elements may move by a good part of lr = 1e-3)
+    # bf16 compute: after step 1 a weight that sits on a bf16 rounding boundary may round differently on the two paths, and an
+    # element whose gradient is below the bf16 noise floor gets a sign-like Adam update: single elements may differ by up to
+    # 2 lr = 2e-3 after two steps, so the bar is on the maximum (< 2 lr) AND on the mean (< lr / 20)
+    tol = 5e-5 if dtype == "fp32" else 2e-3
+    for rank in range(2):
+        got = torch.load(out_path + f".{rank}", weights_only=True)
+        for name, ref_mod in (("params", m), ("ema", ts.ema)):
+            for k, p in ref_mod.named_parameters():
+                if k.endswith("attn.key.bias"):
+                    continue
+                diff_k = (p.detach().cpu() - got[name][k]).abs()
+                err = float(diff_k.max())
+                assert err < tol * max(1.0, float(got[name][k].abs().max())), (rank, name, k, err)
+                assert name == "ema" or float(diff_k.mean()) < 5e-5, (rank, name, k, float(diff_k.mean()))
+        scale = float((want_out - xp2.cpu()).abs().max())
+        assert float((got["out"] - want_out).abs().max()) / scale < (1e-3 if dtype == "fp32" else 3e-2), rank
 
 
 def _rccl_rank(port, out_path):
@@ -327,6 +364,7 @@ def _rccl_rank(port, out_path):
         dp.broadcast_parameters(m)
         diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
         ts = TrainStep(m, diff, lr=1e-3, wd=0.1, grad_clip=0.75, bucket_layers=1)
+        assert ts.shard                       # the default under a process group: reduce_scatter / all_gather really run on RCCL
         for i in range(2):
             ts.step(*_ddp_batch(i))
         rows = torch.arange(5 * 7, dtype=torch.float32, device=DEV).view(5, 7)
