@@ -192,38 +192,122 @@ def backward_into(eng, ws, x, x_prev, d_out, buf, schedule=None):
     del keep
 
 
-class DenoiseFunction(torch.autograd.Function):
-    """autograd node of one denoiser call.  The parameters are explicit inputs so that their AccumulateGrad
-    nodes (and DistributedDataParallel's hooks on them) receive the gradients."""
+def stage_parameter_names(model):
+    """Parameter names by backward stage (gpt_denoiser_backward_stages): 0 = decoder Linears + ln_f; s in 1..L = block L - s;
+    L + 1 = pos_emb, ln_in, encoder Linears.  (The bias gradient of a block's mlp.2 is produced one stage EARLIER, by the
+    LayerNorm backward that yields its output gradient, so it is complete when its own stage returns it.)"""
+    dec = model.decoder
+    Lr = dec.n_layer
+    stages = [[] for _ in range(Lr + 2)]
+    for name, _ in model.named_parameters():
+        if name.startswith("decoder.blocks."):
+            stages[Lr - int(name.split(".")[2])].append(name)
+        elif name.startswith("decoder.output_parameter_projections.") or name.startswith("decoder.ln_f."):
+            stages[0].append(name)
+        else:
+            stages[Lr + 1].append(name)
+    return stages
 
-    @staticmethod
-    def forward(ctx, model, x, t, lt, lp, x_prev, *params):
-        eng, ws, out = forward_keep(model, x, t, lt, lp, x_prev)
-        ctx.model, ctx.eng, ctx.ws = model, eng, ws
-        ctx.save_for_backward(x, x_prev)
-        # The kept activations live in the engine's ONE training workspace: a second grad-enabled forward of the same model
-        # before this call's backward overwrites them (or re-allocates them for a larger batch).  The generation counter
-        # turns that into an error instead of silently wrong gradients; the buffers stay referenced from ctx so that a
-        # re-allocation cannot free memory this backward's descriptor still points at.
-        ctx.keep_gen, ctx.bufs = eng.keep_gen, eng.buffers(keep_activations=True)
-        ctx.versions = tuple(p._version for p in model.parameters())
-        return out
 
-    @staticmethod
-    def backward(ctx, d_out):
-        x, x_prev = ctx.saved_tensors
-        eng = ctx.eng
-        if eng.keep_gen != ctx.keep_gen:
+class _PendingBackward:
+    """What the stage nodes of ONE training forward share: engine, kept-activation workspace, inputs, the gradient arena."""
+
+    def __init__(self, model, eng, ws, x, x_prev):
+        self.model, self.eng, self.ws, self.x, self.x_prev = model, eng, ws, x, x_prev
+        # the kept activations live in the engine's ONE training workspace: a second grad-enabled forward of the same model
+        # before this backward overwrites them (or re-allocates them for a larger batch).  The generation counter turns that
+        # into an error instead of silently wrong gradients; the buffers stay referenced here so that a re-allocation cannot
+        # free memory this backward's descriptor still points at.
+        self.keep_gen, self.bufs = eng.keep_gen, eng.buffers(keep_activations=True)
+        self.versions = tuple(p._version for p in model.parameters())
+        self.buf = self.bw = self.keep = self.d_out = None
+        self.done = 0
+
+    def begin(self, d_out):
+        eng = self.eng
+        if eng.keep_gen != self.keep_gen:
             raise RuntimeError("Gpt: another grad-enabled forward of this model ran before this backward; the HIP path keeps the "
                                "activations of ONE pending forward per model (call backward() after each forward, as "
                                "main.py:47-67 does)")
-        if ctx.versions != tuple(p._version for p in ctx.model.parameters()):
+        if self.versions != tuple(p._version for p in self.model.parameters()):
             raise RuntimeError("G.pt parameters changed between forward and backward")
-        buf = eng.arena.new_buffer()
-        backward_into(eng, ctx.ws, x, x_prev, d_out.detach().float().contiguous(), buf)
-        grads = eng.arena.views(buf, ctx.model)
-        return (None, None, None, None, None, None, *grads)
+        self.d_out = d_out.detach().float().contiguous()
+        self.buf = _gradient_buffer(eng, self.model)
+        self.bw, self.keep = _descriptor(eng, self.buf, _scratch(eng, self.x.shape[0]))
+
+    def run_stage(self, stage):
+        assert stage == self.done, "backward stages run in order"
+        L.check(L.lib().gpt_denoiser_backward_stages(C.byref(self.eng.cmodel), C.byref(self.ws), C.byref(self.bw), L.ptr(self.x),
+                                                     L.ptr(self.x_prev), L.ptr(self.d_out), self.x.shape[0], stage, stage + 1,
+                                                     L.stream()), "gpt_denoiser_backward_stages")
+        self.done = stage + 1
+
+
+def _gradient_buffer(eng, model):
+    """A zeroed gradient arena.  The previous call's arena is reused (one memset instead of a 1.5 GB allocation + fill per
+    iteration) unless some parameter's .grad still aliases it (autograd may adopt a returned gradient as .grad: a caller who
+    accumulates over several backward calls must keep what it holds)."""
+    buf = getattr(eng, "_grad_buf", None)
+    if buf is not None:
+        lo, hi = buf.data_ptr(), buf.data_ptr() + buf.numel() * 4
+        if any(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in model.parameters()):
+            buf = None
+    if buf is None:
+        buf = eng._grad_buf = eng.arena.new_buffer()
+    else:
+        buf.zero_()
+    return buf
+
+
+class _StageFunction(torch.autograd.Function):
+    """One backward stage as its own autograd node.  The nodes of a forward form a chain (the output of stage s + 1 is a
+    one-element carrier fed to stage s), so autograd runs them in stage order and hands every stage's parameter gradients to
+    their AccumulateGrad nodes - and DistributedDataParallel's bucket hooks on them (main.py:229-240) - as soon as that stage
+    has been ENQUEUED: the reducer's all-reduces overlap with the remaining stages, as they do for the reference's per-op graph.
+    The forward itself runs once, as a whole, in the deepest node."""
+
+    @staticmethod
+    def forward(ctx, pending, stage, n_stages, names, carrier, *params):
+        ctx.pending, ctx.stage, ctx.names = pending, stage, names
+        ctx.has_carrier = carrier is not None
+        if stage == 0:
+            return pending.out
+        return pending.x.new_zeros(1)
+
+    @staticmethod
+    def backward(ctx, g):
+        pd = ctx.pending
+        if ctx.stage == 0:
+            pd.begin(g)
+        pd.run_stage(ctx.stage)
+        ar = pd.eng.arena
+        named = dict(pd.model.named_parameters())
+        grads = []
+        for n in ctx.names:
+            o, cnt = ar.slices[n]
+            grads.append(pd.buf[o:o + cnt].view_as(named[n]))
+        carrier_grad = g.new_zeros(1) if ctx.has_carrier else None
+        return (None, None, None, None, carrier_grad, *grads)
+
+
+class DenoiseFunction:
+    """autograd bridge of one denoiser call: n_layer + 2 chained stage nodes (see _StageFunction).  The parameters are explicit
+    inputs of their stage's node so that their AccumulateGrad nodes (and DDP's hooks on them) receive the gradients."""
 
     @staticmethod
     def run(model, x, t, lt, lp, x_prev):
-        return DenoiseFunction.apply(model, x, t, lt, lp, x_prev, *model.parameters())
+        eng, ws, out = forward_keep(model, x, t, lt, lp, x_prev)
+        pending = _PendingBackward(model, eng, ws, x, x_prev)
+        pending.out = out
+        stages = getattr(model, "_stage_names", None)
+        if stages is None:
+            stages = model._stage_names = stage_parameter_names(model)
+        named = dict(model.named_parameters())
+        if not all(p.requires_grad for p in named.values()):
+            raise NotImplementedError("the HIP training path differentiates all G.pt parameters together (freeze none, or run "
+                                      "under torch.no_grad())")
+        n = len(stages)
+        carrier = None
+        for stage in range(n - 1, -1, -1):
+            carrier = _StageFunction.apply(pending, stage, n, stages[stage], carrier, *[named[k] for k in stages[stage]])
+        return carrier

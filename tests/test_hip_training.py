@@ -344,6 +344,120 @@ def test_two_rank_step_equals_full_batch(tmp_path, mode, dtype):
         assert float((got["out"] - want_out).abs().max()) / scale < (1e-3 if dtype == "fp32" else 3e-2), rank
 
 
+def test_autograd_route_delivers_gradients_stage_by_stage():
+    """loss.backward() through the bridge (main.py:47-67): every parameter's gradient reaches its hooks (where DDP's reducer
+    listens) as soon as ITS backward stage is enqueued, not after the whole backward; the arena is reused across iterations
+    unless a .grad still aliases it; results equal the one-call backward."""
+    from gpt_amd import backward as gb
+    m, plan, sd = build("mnist_small", "fp32", seed=21)
+    m.train()
+    x, t, lt, lp, xp = (v.to(DEV) for v in make_inputs("mnist_small", B=4, seed=34))
+    n_stages = m.decoder.n_layer + 2
+    seen, ran = {}, []
+    orig = gb._PendingBackward.run_stage
+
+    def counting(self, stage):
+        ran.append(stage)
+        return orig(self, stage)
+
+    gb._PendingBackward.run_stage = counting
+    try:
+        hooks = [p.register_hook(lambda g, k=k: seen.__setitem__(k, len(ran))) for k, p in m.named_parameters()]
+        out = m(x, t, lt, loss_prev=lp, x_prev=xp)
+        out.square().mean().backward()
+    finally:
+        gb._PendingBackward.run_stage = orig
+        for h in hooks:
+            h.remove()
+    assert ran == list(range(n_stages))
+    stages = gb.stage_parameter_names(m)
+    for s_idx, names in enumerate(stages):
+        for k in names:
+            assert seen[k] == s_idx + 1, (k, seen[k], s_idx)          # delivered right after its own stage
+    g1 = {k: p.grad.clone() for k, p in m.named_parameters()}
+    # one-call backward of the same forward into a fresh arena
+    xx, tt, l1, l2, xpp = m._prepare(x, t, lt, lp, xp)
+    eng, ws, out2 = gb.forward_keep(m, xx, tt, l1, l2, xpp)
+    buf = eng.arena.new_buffer()
+    gb.backward_into(eng, ws, xx, xpp, (2.0 / out2.numel()) * out2, buf)
+    for (k, p), v in zip(m.named_parameters(), eng.arena.views(buf, m)):
+        assert torch.allclose(g1[k], v, rtol=1e-4, atol=1e-6 * float(v.abs().max()) + 1e-12), k
+    # second iteration: zero_grad(set_to_none) as main.py:66 does -> the arena is reused; without it (.grad may alias) it is not
+    first = eng._grad_buf.data_ptr()
+    m.zero_grad(set_to_none=True)
+    m(x, t, lt, loss_prev=lp, x_prev=xp).square().mean().backward()
+    assert eng._grad_buf.data_ptr() == first
+    for k, p in m.named_parameters():
+        assert torch.allclose(p.grad, g1[k], rtol=1e-4, atol=1e-6 * float(g1[k].abs().max()) + 1e-12), k
+    m(x, t, lt, loss_prev=lp, x_prev=xp).square().mean().backward()      # accumulation on top of held gradients
+    for k, p in m.named_parameters():
+        if not k.endswith("attn.key.bias"):
+            assert torch.allclose(p.grad, 2 * g1[k], rtol=1e-3, atol=1e-5 * float(g1[k].abs().max()) + 1e-12), k
+
+
+def _ddp_autograd_rank(rank, world, port, out_path):
+    """The reference's own training iteration (main.py:229-240 + 63-74) on 2 ranks: DistributedDataParallel(static_graph=True)
+    around the HIP Gpt, training_losses(...).backward(), clip, torch AdamW."""
+    import faulthandler
+    import os
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel
+    faulthandler.dump_traceback_later(100, exit=True)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m, plan, sd = build("mnist_small", "fp32", seed=3 + rank)          # DDP broadcasts rank 0's weights at construction
+        m.train()
+        diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
+        ddp = DistributedDataParallel(m, device_ids=[0], output_device=0, static_graph=True)
+        opt = m.configure_optimizers(lr=1e-3, wd=0.1, betas=(0.9, 0.999))
+        for i in range(2):
+            xp, x1, lp, lt, t, w, noise = (v[rank * 4: rank * 4 + 4] for v in _ddp_batch(i))
+            terms = diff.training_losses(ddp, x1, t, model_kwargs=dict(loss_target=lt, loss_prev=lp, x_prev=xp), noise=noise)
+            loss = (terms["loss"] * w).mean()
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(m.parameters(), 0.75)
+            opt.step()
+        if rank == 0:
+            torch.save({k: p.detach().cpu() for k, p in m.named_parameters()}, out_path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ddp_static_graph_through_autograd_equals_full_batch(tmp_path):
+    """main.py unchanged: DDP(static_graph=True) over the autograd bridge on 2 ranks == the full batch on one process."""
+    import socket
+    import torch.multiprocessing as mp
+    from gpt_amd.trainstep import TrainStep
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out_path = str(tmp_path / "ddp.pt")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_ddp_autograd_rank, args=(r, 2, port, out_path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=150)
+        if p.exitcode is None:
+            p.kill()
+        assert p.exitcode == 0
+    got = torch.load(out_path, weights_only=True)
+    m, plan, sd = build("mnist_small", "fp32", seed=3)
+    m.train()
+    diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
+    ts = TrainStep(m, diff, lr=1e-3, wd=0.1, grad_clip=0.75, use_ema=False)
+    for i in range(2):
+        ts.step(*_ddp_batch(i))
+    for k, p in m.named_parameters():
+        if k.endswith("attn.key.bias"):
+            continue
+        assert float((p.detach().cpu() - got[k]).abs().max()) < 5e-5 * max(1.0, float(got[k].abs().max())), k
+
+
 def _rccl_rank(port, out_path):
     """The multi-GPU code path on RCCL with the one rank a one-GPU box allows (GPT_DP_REHEARSE=1, dp.exchanging()):
     parameter broadcast, bucketed asynchronous gradient all-reduces on RCCL's stream overlapped with the backward stages,
