@@ -247,12 +247,19 @@ def secondary_sample(args, device, world, rank, line, key, case, dtype, batch, s
     return out
 
 
+def _latest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round that committed one."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return found[-1] if found else None
+
+
 def pmc_traffic(case, B, dtype):
     """Bytes per GEMM launch behind L2 from the PMC passes committed under profiles/ (FETCH_SIZE x 2 on gfx950 +
     WRITE_SIZE, collected with rocprofv3 --pmc on this same command): counters cannot be read from inside the run, so
     the figure is only reported for the workload it was collected on, else null."""
-    path = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
-    if (case, B, dtype) != ("mnist", 320, "bf16") or not os.path.exists(path):
+    path = _latest_profile("gemm_traffic.json")
+    if (case, B, dtype) != ("mnist", 320, "bf16") or path is None:
         return None
     with open(path) as f:
         return json.load(f)["traffic_bytes_per_launch"]
@@ -262,8 +269,8 @@ def pmc_mfma_util(case, B, dtype):
     """Fraction of the chip's matrix-pipe cycles that were busy while the GEMM kernels ran, from the PMC pass committed under
     profiles/ (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 256 CUs x 4 SIMDs), tools/pmc_mfma.py, same command): like
     `traffic` it cannot be read from inside the run, so it is reported for the workload it was collected on only."""
-    path = os.path.join(ROOT, "profiles", "r01_mfma_util.json")
-    if (case, B, dtype) != ("mnist", 320, "bf16") or not os.path.exists(path):
+    path = _latest_profile("mfma_util.json")
+    if (case, B, dtype) != ("mnist", 320, "bf16") or path is None:
         return None
     with open(path) as f:
         rows = [v for k, v in json.load(f).items() if "gemm256_kernel" in k or "gemm_nt_kernel" in k]
@@ -340,7 +347,8 @@ def bench_sample(args, device, world, rank, cpu=True):
         line["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK[args.dtype], "unit": "TFLOP/s",
                             "frac": achieved / PEAK[args.dtype], "traffic": pmc_traffic(case, B, args.dtype),
                             "mfma_util_pmc": pmc_mfma_util(case, B, args.dtype),
-                            "kernel": "gemm256_kernel + gemm_nt_kernel K spans of fc1's row tail (qkv/proj/fc1/fc2 contractions, 5 GEMM calls per layer)", "launches": nl.value,
+                            "kernel": "gemm256_kernel (+ gemm_nt_kernel for row tails): the qkv / proj / fc1 / fc2 contractions of every layer",
+                            "launches": nl.value,
                             "avg_launch_us": ms.value * 1e3 / max(nl.value, 1),
                             "flops_per_launch": fl.value / max(nl.value, 1)}
     if cpu and rank == 0 and world == 1 and not args.no_cpu_baseline:

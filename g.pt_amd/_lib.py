@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPT_HIP_LIB") or os.path.join(_HERE, "lib", "libgpt_hip.so")   # override: kernel experiments
 
 F32, BF16 = 0, 1
+DP_I64, DP_ID_BYTES = 2, 128
 EPI_STORE, EPI_GELU, EPI_RESADD, EPI_STORE_F32, EPI_GELU_AUX, EPI_DGELU, EPI_ACCUM_F32 = range(7)
 MAX_TOKENS = 40
 SRC_X, SRC_XPREV, SRC_SCALAR = 0, 1, 2
@@ -113,6 +114,16 @@ _PROTOS = {
                             i32, vp], i32),
     "gpt_pack_segments": ([vp, vp, i32, vp, i32, i64, vp], i32),
     "gpt_pack_tensors": ([vp, i32, i64, vp], i32),
+    "gpt_dp_unique_id": ([vp], i32),
+    "gpt_dp_init": ([vp, i32, i32], i32),
+    "gpt_dp_destroy": ([], i32),
+    "gpt_dp_rank": ([], i32),
+    "gpt_dp_world": ([], i32),
+    "gpt_dp_allreduce_grads": ([vp, i64, vp], i32),
+    "gpt_dp_reduce_scatter": ([vp, vp, i64, i32, vp], i32),
+    "gpt_dp_allgather": ([vp, vp, i64, i32, vp], i32),
+    "gpt_dp_broadcast": ([vp, i64, i32, i32, vp], i32),
+    "gpt_dp_barrier": ([vp], i32),
     "gpt_sample_loop": ([C.POINTER(Model), C.POINTER(Workspace), vp, vp, vp, i32, vp, vp, C.POINTER(i64), i32, i32,
                          i32, i32, i32, f32, f32, vp, u64, vp, vp, vp, vp, i32, vp], i32),
     "gpt_ddim_sample_loop": ([C.POINTER(Model), C.POINTER(Workspace), vp, vp, vp, i32, vp, vp, vp, f32, C.POINTER(i64), i32,

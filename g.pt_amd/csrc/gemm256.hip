@@ -84,10 +84,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
 
   const int nk_span = (nk_tile + g.ksplit - 1) / g.ksplit, kt0 = span * nk_span;
   const int tile = swz, nk = min(nk_span, nk_tile - kt0);   // host: every span gets at least one K-tile
-  // tile order inside an XCD's contiguous run: column groups of GROUP_N tiles, rows fastest across the group, so
-  // the ~32 tiles an XCD works on at once form a ~4 x 8 block (A and W panels both re-used from its 4 MiB L2)
+  // tile order inside an XCD's contiguous run: column groups of GROUP_N tiles, columns fastest inside a group, so the 32
+  // tiles an XCD works on at once form an 8-row x 4-column block: its 4 W panels (3 MiB at K = 1536) stay in the XCD's 4 MiB
+  // L2 from one round of tiles to the next while the A panels stream.  r02 PMC (FETCH_SIZE) with groups of 8: qkv fetched
+  // 239 MB per launch for 40 MB of operands - every round of 32 tiles re-read 4 A + 8 W panels (9 MiB > L2); timing is
+  // insensitive (groups of 2 / 4 / 8 / 16: 489.7 / 483.5 / 486.3 / 495.1 us per layer, the re-reads are Infinity-Cache hits)
 #ifndef GPT_GROUP_N
-#define GPT_GROUP_N 8
+#define GPT_GROUP_N 4
 #endif
   constexpr int GROUP_N = GPT_GROUP_N;
   const int tiles_m = (g.M + BM - 1) / BM;

@@ -424,6 +424,35 @@ int gpt_adamw_ema_step(float* params, float* grads, float* exp_avg, float* exp_a
 int gpt_pack_segments(const float* params, void* packed, int packed_dtype, const gpt_opt_segment_t* segments,
                       int n_segments, int64_t n, void* stream);
 
+/* ---- data-parallel collectives on RCCL over xGMI (dp_init / dp_destroy / dp_allreduce_grads / dp_allgather /
+ * dp_broadcast / dp_barrier) -------------------------------------------------------------------------------------------------
+ * For callers that do not use torch.distributed (the Python host's default route, whose "nccl" backend is the same RCCL).
+ * One communicator per process, one process per GPU (main.py:344-354); librccl is loaded on first use.  Rank 0 obtains an id
+ * with gpt_dp_unique_id and hands its GPT_DP_ID_BYTES bytes to the other ranks by any channel (the reference uses a TCP store,
+ * main.py:328-333); every rank then calls gpt_dp_init with the device it will use current.  All calls are stream-ordered and
+ * in place where one buffer is given; counts are elements of `dtype` (GPT_F32, GPT_BF16, GPT_DP_I64).  Status: 0 ok, negative =
+ * rejected, >= 1000 = 1000 + ncclResult_t. */
+#define GPT_DP_ID_BYTES 128
+#define GPT_DP_I64 2
+int gpt_dp_unique_id(void* host_id_out);
+int gpt_dp_init(const void* host_id, int rank, int world);
+int gpt_dp_destroy(void);
+int gpt_dp_rank(void);
+int gpt_dp_world(void);
+/* grads[n] (fp32) = SUM over ranks, in place: the gradient exchange of DistributedDataParallel (main.py:229-240); the 1/world
+ * scale is folded into gpt_adamw_ema_step's grad_scale. */
+int gpt_dp_allreduce_grads(float* grads, int64_t n, void* stream);
+/* The two halves of that exchange for the sharded optimizer step (g.pt_amd/trainstep.py): recv[recv_count] = SUM over ranks of
+ * send[rank * recv_count ...] (send holds world * recv_count elements); recv[world * send_count] = every rank's send[send_count]
+ * (send may be recv + rank * send_count: in place).  gpt_dp_allgather is also Gpt/distributed.py:170-183 (all_gather). */
+int gpt_dp_reduce_scatter(const void* send, void* recv, int64_t recv_count, int dtype, void* stream);
+int gpt_dp_allgather(const void* send, void* recv, int64_t send_count, int dtype, void* stream);
+/* buf[count] = root's buf (initial parameter broadcast of DDP, main.py:231-236; rank0_to_all, Gpt/distributed.py:186-189). */
+int gpt_dp_broadcast(void* buf, int64_t count, int dtype, int root, void* stream);
+/* synchronize() (Gpt/distributed.py:152-157): a one-word all-reduce, then the host waits for `stream` - the one entry point
+ * that synchronises. */
+int gpt_dp_barrier(void* stream);
+
 /* The same copies for parameters held as SEPARATE tensors (the reference's nn.Module keeps 235 of them): one
  * launch over a DEVICE table of items.  Item i: `count` fp32 elements at src (16-byte aligned) are written to dst (16-byte
  * aligned) as dst_dtype (GPT_F32 / GPT_BF16), element j at dst[(j / k) * ld + j % k] (k == ld: a plain cast copy; ld > k: rows

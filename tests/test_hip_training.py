@@ -601,3 +601,51 @@ torch.save({k: p.grad.cpu() for k, p in m.named_parameters()}, sys.argv[1])
     for k in outs[0]:
         a, b = outs[0][k], outs[1][k]
         assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-12) + 1e-9, k
+
+
+def _native_dp_rank(out_path):
+    """gpt_dp_* (include/gpt_hip.h) with the one rank a one-GPU box allows: every collective really runs on RCCL; with one rank
+    each is the identity, so values are checked exactly."""
+    import ctypes as C
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=True)
+    torch.cuda.set_device(0)
+    lib, st = L.lib(), L.stream()
+    assert lib.gpt_dp_allreduce_grads(None, 4, st) < 0 and b"gpt_dp_init first" in lib.gpt_last_error()
+    uid = (C.c_char * L.DP_ID_BYTES)()
+    L.check(lib.gpt_dp_unique_id(uid), "gpt_dp_unique_id")
+    assert lib.gpt_dp_init(uid, 1, 1) < 0                          # rank out of range: rejected before RCCL sees it
+    L.check(lib.gpt_dp_init(uid, 0, 1), "gpt_dp_init")
+    assert lib.gpt_dp_rank() == 0 and lib.gpt_dp_world() == 1
+    assert lib.gpt_dp_init(uid, 0, 1) < 0                          # one communicator per process
+    g = torch.arange(1000, dtype=torch.float32, device=DEV)
+    L.check(lib.gpt_dp_allreduce_grads(L.ptr(g), g.numel(), st), "allreduce")
+    rs = torch.zeros(1000, device=DEV)
+    L.check(lib.gpt_dp_reduce_scatter(L.ptr(g), L.ptr(rs), 1000, L.F32, st), "reduce_scatter")
+    h = torch.arange(64, device=DEV).bfloat16()
+    ag = torch.zeros(64, dtype=torch.bfloat16, device=DEV)
+    L.check(lib.gpt_dp_allgather(L.ptr(h), L.ptr(ag), 64, L.BF16, st), "allgather")
+    L.check(lib.gpt_dp_allgather(L.ptr(h), L.ptr(h), 64, L.BF16, st), "allgather in place")
+    t = torch.arange(7, device=DEV)
+    L.check(lib.gpt_dp_broadcast(L.ptr(t), 7, L.DP_I64, 0, st), "broadcast")
+    assert lib.gpt_dp_broadcast(L.ptr(t), 7, 5, 0, st) < 0          # unknown dtype
+    L.check(lib.gpt_dp_barrier(st), "barrier")                      # synchronises the stream
+    ok = (torch.equal(g, torch.arange(1000, dtype=torch.float32, device=DEV)) and torch.equal(rs, g) and torch.equal(ag, h)
+          and torch.equal(t, torch.arange(7, device=DEV)))
+    L.check(lib.gpt_dp_destroy(), "destroy")
+    assert lib.gpt_dp_world() == 1 and lib.gpt_dp_destroy() == 0
+    torch.save({"ok": ok}, out_path)
+
+
+def test_native_rccl_entry_points_one_rank(tmp_path):
+    """The C-ABI collectives (dp_init / dp_allreduce_grads / dp_allgather / dp_broadcast / dp_barrier /
+    dp_destroy) on RCCL itself, loaded with dlopen by the library."""
+    import torch.multiprocessing as mp
+    out_path = str(tmp_path / "dp.pt")
+    p = mp.get_context("spawn").Process(target=_native_dp_rank, args=(out_path,))
+    p.start()
+    p.join(timeout=150)
+    if p.exitcode is None:
+        p.kill()
+    assert p.exitcode == 0
+    assert torch.load(out_path, weights_only=True)["ok"]
