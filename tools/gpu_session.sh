@@ -1,9 +1,10 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 1100 python -u -m pytest tests -x -q --timeout 400 --timeout-method thread -m gpu > gpurun_out/r2_gpu_all.log 2>&1; rc1=$?
-tail -3 gpurun_out/r2_gpu_all.log | cut -c1-300
+timeout -k 10 300 python -u -m pytest tests/test_hip_parity.py -x -q --timeout 200 --timeout-method thread -m gpu -k "gemm" > gpurun_out/r2_gemm_tests.log 2>&1; rc1=$?
+tail -2 gpurun_out/r2_gemm_tests.log
 [ $rc1 -eq 0 ] || exit $rc1
-timeout -k 10 100 python -c "import __graft_entry__ as g; g.smoke()" || exit 1
-timeout -k 10 600 python bench.py > gpurun_out/r2_bench1.json 2> gpurun_out/r2_bench1.err; rc2=$?
-tail -3 gpurun_out/r2_bench1.err; echo "rc bench=$rc2"
-timeout -k 10 300 python bench.py --batch 64 --no-train --no-extra --no-cpu-baseline > gpurun_out/r2_bench_b64.json 2>/dev/null
+for rep in 1 2; do
+for lib in libgpt_hip_nobal.so libgpt_hip.so; do
+  echo "== $lib rep $rep"
+  GPT_HIP_LIB=$PWD/g.pt_amd/lib/$lib timeout -k 10 120 python tools/gemm_bench.py --rounds 30 2>/dev/null || exit 1
+done; done
