@@ -6,6 +6,7 @@ Gradients are produced into ONE flat fp32 arena; each parameter's gradient is a 
 value weight gradients of a layer are three consecutive slices of the fused [3d, d] gradient the kernels write).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -132,7 +133,15 @@ def _scratch(eng, B):
     return s
 
 
-def _descriptor(eng, buf, scratch):
+def can_overwrite_wgrads(eng, B):
+    """True where gpt_denoiser_backward computes the Blocks' weight gradients by the grouped TN launch, which can store them
+    instead of accumulating (gpt_backward_t.wgrad_overwrite)."""
+    dec = eng.model.decoder
+    return eng.code == L.BF16 and (B * dec.block_size) % 64 == 0 and dec.n_embd % 256 == 0 and \
+        os.environ.get("GPT_WGRAD_TN", "1") != "0" and os.environ.get("GPT_WGRAD_OVERWRITE", "1") != "0"
+
+
+def _descriptor(eng, buf, scratch, overwrite=False):
     dec = eng.model.decoder
     ar = eng.arena
     base = buf.data_ptr()
@@ -153,6 +162,7 @@ def _descriptor(eng, buf, scratch):
         bw.g_dec_w[j] = base + 4 * o
     for k, t in scratch.items():
         setattr(bw, k, L.ptr(t))
+    bw.wgrad_overwrite = int(overwrite)
     return bw, layers
 
 
@@ -170,15 +180,17 @@ def forward_keep(model, x, t, lt, lp, x_prev):
     return eng, ws, out
 
 
-def backward_into(eng, ws, x, x_prev, d_out, buf, schedule=None):
+def backward_into(eng, ws, x, x_prev, d_out, buf, schedule=None, overwrite=False):
     """Runs the backward of the last forward_keep on this engine, accumulating into the flat buffer `buf`.
 
+    overwrite: the Blocks' weight gradients are stored, not accumulated (their part of `buf` need not be zero; only where
+    can_overwrite_wgrads holds).
     schedule: optional [(stage_end, callback)] with increasing stage_end (stages as in gpt_denoiser_backward_stages):
     each callback is called on the host right after the stages before its stage_end have been enqueued - the hook the
     training step uses to put the gradient all-reduce of finished layers in flight behind them."""
     B = x.shape[0]
     scratch = _scratch(eng, B)
-    bw, keep = _descriptor(eng, buf, scratch)
+    bw, keep = _descriptor(eng, buf, scratch, overwrite)
     n_stages = eng.model.decoder.n_layer + 2
     done = 0
     for stage_end, callback in list(schedule or []) + [(n_stages, None)]:

@@ -248,6 +248,8 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
   // launches of 36 ... 144 tiles.  Until then mlp.2's dY must survive the LayerNorm backward that would overwrite it: that
   // LayerNorm writes its operand copy to bw->tA (the NT fallback's transpose scratch, [4d, Mp] >= [M, d], unused on this path).
   const bool grouped = use_tn && dt == GPT_BF16 && M % 64 == 0 && d % 256 == 0;
+  GPT_REQUIRE(!bw->wgrad_overwrite || grouped,
+              "gpt_denoiser_backward: wgrad_overwrite needs the grouped TN launch (bf16, B * T %% 64 == 0, n_embd %% 256 == 0)");
   for (int l = L - 1; l >= 0; --l) {
     if (L - l < stage_begin || L - l >= stage_end) continue;
     const gpt_layer_t& ly = m->layers[l];
@@ -283,7 +285,7 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
       float* Cg[4] = {gl.g_w2, gl.g_w1, gl.g_wqkv, gl.g_wproj};
       const int I[4] = {d, 4 * d, 3 * d, d}, J[4] = {4 * d, d, d, d};
       const int64_t ldp[4] = {d, 4 * d, 3 * d, d}, ldq[4] = {4 * d, d, d, d}, ldc[4] = {4 * d, d, d, d};
-      CHECK(gpt_gemm_tn_grouped(4, P, ldp, Q, ldq, Cg, ldc, I, J, M, 1, stream));
+      CHECK(gpt_gemm_tn_grouped(4, P, ldp, Q, ldq, Cg, ldc, I, J, M, bw->wgrad_overwrite ? 0 : 1, stream));
     } else {
       CHECK(wgrad(bw->d_qkv, 3 * d, h1, d, gl.g_wqkv));
     }

@@ -21,7 +21,7 @@ import torch.distributed as dist
 
 from . import _lib as L
 from . import dp
-from .backward import _ensure_training_state, backward_into, forward_keep
+from .backward import _ensure_training_state, backward_into, can_overwrite_wgrads, forward_keep
 from .ddpm import ModelMeanType
 from .flat import FlatState
 
@@ -223,7 +223,10 @@ class TrainStep:
         if self._t_ready is not None:
             torch.cuda.current_stream().wait_event(self._t_ready)
             self._t_ready = None
-        backward_into(eng, ws, x, xp, d_out, self.grads, schedule)
+        # the Blocks' weight gradients (95 % of the arena) are STORED by the grouped weight-gradient launch where it applies:
+        # no read-modify-write of the arena in its epilogue, and update() zeroes only what is still accumulated
+        self._overwrote = self.fused and can_overwrite_wgrads(eng, B)
+        backward_into(eng, ws, x, xp, d_out, self.grads, schedule, overwrite=self._overwrote)
         return mse
 
     @torch.no_grad()
@@ -270,8 +273,17 @@ class TrainStep:
             if self.grad_clip > 0:
                 L.check(lib.gpt_grad_sumsq(L.ptr(self.grads), n, L.ptr(self.norm_scratch), L.ptr(self.grad_norm_sq), st),
                         "gpt_grad_sumsq")
-            seg, n_seg = self.flat.segments(self.code)
-            adamw(0, n, self.grads, 0, seg, n_seg, 1)
+            if getattr(self, "_overwrote", False):
+                # block weights: nothing to zero (the next backward overwrites them); the rest still accumulates
+                cut = self.arena.s_dec_start
+                if not hasattr(self, "_seg_split"):
+                    self._seg_split = (self.flat.segment_table(self.code, 0, cut), self.flat.segment_table(self.code, cut, n))
+                (sa, na), (sb, nb) = self._seg_split
+                adamw(0, cut, self.grads, 0, sa, na, 0)
+                adamw(cut, n - cut, self.grads[cut:], cut, sb, nb, 1)
+            else:
+                seg, n_seg = self.flat.segments(self.code)
+                adamw(0, n, self.grads, 0, seg, n_seg, 1)
         else:
             r0 = self.arena.r_start
             if self.grad_clip > 0:
@@ -289,7 +301,10 @@ class TrainStep:
             for (lo, hi, c, own, g_off), (seg, n_seg) in zip(self.s_chunks, self.seg_tables):
                 adamw(own, c, self.gshard[g_off:], g_off, seg, n_seg, 0)
             adamw(r0, self.n_rep, self.grads[r0:], self.n_own, self.seg_rep[0], self.seg_rep[1], 0)
-            self.grads.zero_()
+            if getattr(self, "_overwrote", False):
+                self.grads[self.arena.s_dec_start:].zero_()      # decoder Linears + region R: all that is still accumulated
+            else:
+                self.grads.zero_()
             # the updated operands of every rank's shard: bf16 copies in bf16 compute mode (half the bytes), else the fp32 parameters
             if self.code == L.BF16:
                 self._gather(packed, "_params_stale")

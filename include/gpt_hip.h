@@ -335,6 +335,11 @@ typedef struct {
   void* tA;        /* scratch (dtype) [4d, Mp]  transposed operand, Mp = M rounded up to 64 */
   void* tB;        /* scratch (dtype) [4d, Mp]                                       */
   float* d_tok;    /* scratch fp32 [M, d]   decoder / encoder token gradients        */
+  /* != 0: the four weight gradients of every Block (g_wqkv, g_wproj, g_w1, g_w2) are STORED, not accumulated: they need no
+   * zeroing before the call and are not read (no read-modify-write of 12 d^2 floats per Block).  Only valid where the grouped
+   * TN launch computes them (GPT_BF16, B * T % 64 == 0, n_embd % 256 == 0); rejected otherwise.  Every other gradient is
+   * accumulated as before. */
+  int wgrad_overwrite;
 } gpt_backward_t;
 
 /* Backward of gpt_denoiser_forward run on a layer_stride == 1 workspace: d_out[B, D] = dLoss/d(out).

@@ -241,6 +241,45 @@ def test_fused_step_matches_torch_optimizer_over_steps():
             assert float((a[k] - b[k]).abs().max()) < 2e-4 * max(1.0, float(b[k].abs().max())), k
 
 
+def test_store_mode_weight_gradients_equal_accumulation(monkeypatch):
+    """Where the grouped weight-gradient launch applies (bf16, B * T % 64 == 0, d % 256 == 0) TrainStep has the Blocks' weight
+    gradients STORED and stops zeroing their part of the arena: three steps must give the parameters of the accumulate-into-zero
+    path (a + 0 is exact; LayerNorm / bias gradients are atomically summed, hence a tolerance), and the arena really holds stale
+    block-weight gradients in between."""
+    from gpt_amd.trainstep import TrainStep
+    diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
+    runs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("GPT_WGRAD_OVERWRITE", flag)
+        m, plan, sd = build("cifar_small", "bf16", seed=4)
+        m.train()
+        ts = TrainStep(m, diff, lr=1e-3, wd=0.1, grad_clip=0.75)
+        for i in range(3):
+            _, _, lt, lp, xp = (v.to(DEV) for v in make_inputs("cifar_small", B=32, seed=150 + i))
+            gen = torch.Generator().manual_seed(170 + i)
+            x1 = xp + 0.1 * torch.randn(xp.shape, generator=gen).to(DEV)
+            t = torch.randint(0, 1000, (32,), generator=gen).to(DEV)
+            noise = torch.randn(xp.shape, generator=gen).to(DEV)
+            ts.step(xp, x1, lp, lt, t, noise=noise)
+        assert ts._overwrote == (flag == "1")
+        cut = ts.arena.s_dec_start
+        assert float(ts.grads[cut:].abs().max()) == 0.0                        # what still accumulates is zeroed
+        assert (float(ts.grads[:cut].abs().max()) > 0.0) == (flag == "1")      # stored gradients are simply left behind
+        runs.append({k: p.detach().float().cpu() for k, p in m.named_parameters()})
+    for k in runs[0]:
+        if k.endswith("attn.key.bias"):
+            continue
+        assert float((runs[0][k] - runs[1][k]).abs().max()) < 2e-4 * max(1.0, float(runs[1][k].abs().max())), k
+    # a batch the grouped launch does not take (B * T % 64 != 0): the flag must stay off and the step must work
+    m, plan, sd = build("cifar_small", "bf16", seed=4)
+    m.train()
+    ts = TrainStep(m, diff, lr=1e-3, wd=0.1, grad_clip=0.75)
+    monkeypatch.setenv("GPT_WGRAD_OVERWRITE", "1")
+    _, _, lt, lp, xp = (v.to(DEV) for v in make_inputs("cifar_small", B=5, seed=1))
+    ts.step(xp, xp + 0.1, lp, lt, torch.zeros(5, dtype=torch.long, device=DEV))
+    assert not ts._overwrote and float(ts.grads.abs().max()) == 0.0
+
+
 # ---------------------------------------------------------------------------------------------- data parallel
 def _ddp_rank(rank, world, port, out_path, mode="replicated", dtype="fp32"):
     """One rank of a 2-process data-parallel step; both ranks use GPU 0 (the box has one), so the exchange runs on gloo.
