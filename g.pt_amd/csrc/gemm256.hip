@@ -48,6 +48,11 @@ namespace {
 constexpr int RB = 128;             // bytes of K per LDS row
 constexpr int HALF = 128 * RB;      // 16 KiB half-tile: 128 LDS rows
 constexpr int BUF = 4 * HALF;       // A-h0 | A-h1 | W-h0 | W-h1
+// diagnostic builds only (tools/gemm_ablate.sh; results are garbage): bit 0 = no DMA in the steady loop, bit 1 = no fragment
+// reads, bit 2 = no barriers in the loop
+#ifndef GPT_ABL
+#define GPT_ABL 0
+#endif
 constexpr int LDS_BYTES = 2 * BUF;  // 128 KiB
 
 // 128-byte rows: chunk c of LDS row r lives at chunk c ^ ((r >> 1) & 7): conflict-free ds_read_b128
@@ -115,11 +120,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
       srcW[h][p] = g.W + (int64_t)gn * g.ldw + lc * EPC + (int64_t)kt0 * BK;
     }
   }
-  auto dma = [&](const T* const (&src)[2], int kt, int slot) {
-    char* dst = smem + (kt & 1) * BUF + slot * HALF + wid * 2048;
+  auto dma_at = [&](const T* const (&src)[2], int kt, int off) {
+    if ((GPT_ABL & 1) && kt >= 2) return;
+    char* dst = smem + off + wid * 2048;
     __builtin_amdgcn_global_load_lds((gptr_t)(src[0] + kt * BK), (lptr_t)dst, 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gptr_t)(src[1] + kt * BK), (lptr_t)(dst + 1024), 16, 0, 0);
   };
+  auto dma = [&](const T* const (&src)[2], int kt, int slot) { dma_at(src, kt, (kt & 1) * BUF + slot * HALF); };
 
   // bf16: 16x16x32 MFMAs, 8 x 4 accumulator tiles of 16 x 16 (the chip holds a higher clock on this shape than on
   // 32x32x16 at the same cycles per FLOP and the same LDS traffic: +4...8 % measured);  fp32: 32x32x2, 4 x 2 tiles of 32 x 32
@@ -178,6 +185,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
   // fragment reads of one half-tile: A half = 64 rows of this wave (base row wr * 64), W half = 32 columns (base wc * 32)
   const int l15 = lane & 15, l4 = lane >> 4;
   auto read_a = [&](u32x4 (&a)[2][4], const char* half, int h) {
+    if (GPT_ABL & 2) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" : "=v"(a[i >> 2][i & 3]));
+      return;
+    }
     if constexpr (M16) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -192,6 +204,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
     }
   };
   auto read_b = [&](u32x4 (&b)[4], const char* half) {
+    if (GPT_ABL & 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" : "=v"(b[i]));
+      return;
+    }
     if constexpr (M16) {
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj)
@@ -207,11 +224,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
   // multiplies, its SIMD partner reads LDS and issues DMA; the matrix pipe alternates between the two.
   // Because of the offset a wave retires (vmcnt) the DMA of a half-tile ONE PHASE BEFORE the phase that reads
   // it: the other group's pieces are then covered by a barrier that group has passed as well.
-#define SEG_BARRIER()                        \
-  do {                                       \
-    __builtin_amdgcn_sched_barrier(0);       \
-    __builtin_amdgcn_s_barrier();            \
-    __builtin_amdgcn_sched_barrier(0);       \
+#define SEG_BARRIER()                                  \
+  do {                                                 \
+    __builtin_amdgcn_sched_barrier(0);                 \
+    if (!(GPT_ABL & 4)) __builtin_amdgcn_s_barrier();  \
+    __builtin_amdgcn_sched_barrier(0);                 \
   } while (0)
 #define SEG_READS_DONE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
@@ -221,6 +238,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
   //   P1: reads A-h1 (8)                            -> (A-h1 x W-h1), (A-h1 x W-h0);   refills A-h0, W-h0, W-h1 (kt+2)
   // Retire-one-phase-ahead waits: P0 retires A-h1(kt) (6 younger DMA instructions), P1 retires the three half-tiles of
   // kt+1 (2 younger).
+  // (r02: W-h1 in a ring of three slots, so that the refills are 4 + 4 instructions per wave and phase instead of 2 + 6 with
+  // every half-tile still >= 3 phases ahead of its reads, changed nothing: 470 -> 475 us per layer; removed.  The ablation of
+  // this loop - tools/gemm_ablate.sh, DESIGN.md section 4 - puts the loss in the LDS array, not in the issue order.)
   if (nk >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   STAMP(1);
