@@ -38,6 +38,7 @@ namespace gemmk {
 GemmProf g_prof;
 int gemm256_bf16(const GemmArgs<bf16_t>& g, int epi, int rt, hipStream_t s);  // gemm256.hip; rt = 8 | 7 (256- / 224-row tiles)
 int gemm256_f32(const GemmArgs<float>& g, int epi, hipStream_t s);
+int gemm128_bf16(const GemmArgs<bf16_t>& g, int epi, hipStream_t s);          // gemm128.hip: 128 x 256 tiles, three stages
 }
 
 namespace {
@@ -422,6 +423,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(const float* __re
 
 int n_cus();
 
+// 128-row tiles: the three-stage 128 x 256 kernel (gemm128.hip); GPT_GEMM_128=0 falls back to the 256 x 256 kernel with half of
+// every wave's rows switched off (the r01 route, kept for A/B measurements)
+int half_height_bf16(const GemmArgs<bf16_t>& g, int epi, hipStream_t s) {
+  static const bool k128 = [] { const char* e = getenv("GPT_GEMM_128"); return !e || atoi(e) != 0; }();
+  return k128 ? gemm128_bf16(g, epi, s) : gemm256_bf16(g, epi, 4, s);
+}
+
 // spans for a problem of `tiles` 256 x 256 tiles and nk K-tiles: fill the CUs once, keep >= 16 K-tiles per span, fit the
 // workspace; 1 = do not split
 template <typename T>
@@ -536,7 +544,7 @@ int dispatch(const GemmArgs<T>& g, int epi, hipStream_t s) {
     // every tile on a CU of its own and 256-row tiles would leave half the CUs idle: M = 1664, N = 4608 39.9 -> 32.8 us
     static const bool rt4 = [] { const char* e = getenv("GPT_GEMM_RT4"); return !e || atoi(e) != 0; }();
     const int tiles128 = ((g.M + 127) / 128) * ((g.N + 255) / 256);
-    if (rt4 && k_ok && tile_mode() == 0 && tiles256 < 128 && tiles128 > 128 && tiles128 <= n_cus()) return gemm256_bf16(g, epi, 4, s);
+    if (rt4 && k_ok && tile_mode() == 0 && tiles256 < 128 && tiles128 > 128 && tiles128 <= n_cus()) return half_height_bf16(g, epi, s);
   }
   if (k_ok && (tile_mode() == 3 || (tile_mode() == 0 && tiles256 >= 128))) {
     int m_main = g.M;
@@ -650,7 +658,7 @@ extern "C" int gpt_gemm_resadd_layernorm(int dtype, const void* A, int64_t lda, 
   }
   GemmArgs<bf16_t> part{(const bf16_t*)A, (const bf16_t*)W, nullptr, split_ws().ptr, nullptr, lda, ldw, N, 0, M, N, K};
   part.ksplit = sp;
-  const int rc = gemm256_bf16(part, GPT_EPI_STORE_F32, rt, s);
+  const int rc = rt == 4 ? half_height_bf16(part, GPT_EPI_STORE_F32, s) : gemm256_bf16(part, GPT_EPI_STORE_F32, rt, s);
   if (rc != 0) return rc;
   const dim3 grid((M + 3) / 4), block(256);
 #define RLN(NV) hipLaunchKernelGGL((splitk_reduce_ln_kernel<NV, bf16_t>), grid, block, 0, s, split_ws().ptr, sp, bias, resid, ldr, x, \
