@@ -21,7 +21,7 @@ vp, i32, i64, u64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_fl
 
 class Layer(C.Structure):
     _fields_ = [(n, vp) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "wqkv", "bqkv", "wproj", "bproj",
-                                  "w1", "b1", "w2", "b2")]
+                                  "w1", "b1", "w2", "b2", "ready")]
 
 
 class Model(C.Structure):
@@ -31,7 +31,7 @@ class Model(C.Structure):
                [("enc_w", vp * MAX_TOKENS), ("enc_w_ld", i64 * MAX_TOKENS), ("enc_k", i32 * MAX_TOKENS),
                 ("enc_src", i32 * MAX_TOKENS), ("enc_off", i32 * MAX_TOKENS),
                 ("dec_w", vp * MAX_TOKENS), ("dec_n", i32 * MAX_TOKENS), ("dec_off", i32 * MAX_TOKENS),
-                ("layers", C.POINTER(Layer))]
+                ("layers", C.POINTER(Layer)), ("dec_ready", vp)]
 
 
 class LayerGrad(C.Structure):

@@ -13,6 +13,15 @@
 
 static inline size_t esize(int dtype) { return dtype == GPT_BF16 ? 2 : 4; }
 
+// operands delivered asynchronously (gpt_layer_t.ready / gpt_model_t.dec_ready): everything launched on `stream` after this
+// call runs after the event
+static int wait_ready(const void* ev, void* stream) {
+  if (!ev) return 0;
+  const hipError_t e = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0);
+  GPT_REQUIRE(e == hipSuccess, "gpt_denoiser_forward: hipStreamWaitEvent failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
 static int validate(const gpt_model_t* m, const gpt_workspace_t* ws, int B, const char* who) {
   GPT_REQUIRE(m && ws, "%s: null model/workspace", who);
   GPT_REQUIRE(m->dtype == GPT_F32 || m->dtype == GPT_BF16, "%s: bad dtype %d", who, m->dtype);
@@ -87,6 +96,7 @@ static int denoiser_forward(const gpt_model_t* m, const gpt_workspace_t* ws, con
     void* att = lay(ws->att, l, d);
     void* h2 = lay(ws->h2, l, d);
     void* act = lay(ws->act, l, 4 * (size_t)d);
+    CHECK(wait_ready(ly.ready, stream));
     CHECK(gpt_gemm_nt(dt, h1, d, ly.wqkv, d, ly.bqkv, qkv, 3 * d, nullptr, 0, M, 3 * d, d, GPT_EPI_STORE, stream));
     CHECK(gpt_attention(dt, qkv, att, B, T, m->n_head, d / m->n_head, stream));
     CHECK(gpt_gemm_resadd_layernorm(dt, att, d, ly.wproj, d, ly.bproj, xin, d, xmid, d, ly.ln2_w, ly.ln2_b, h2, stat(2 + 2 * l, 0),
@@ -107,6 +117,7 @@ static int denoiser_forward(const gpt_model_t* m, const gpt_workspace_t* ws, con
     CHECK(gpt_gemm_resadd_layernorm(dt, act, 4 * d, ly.w2, 4 * d, ly.b2, xmid, d, xout, d, nw, nb, nh, stat(ns, 0), stat(ns, 1), M, d,
                                     4 * d, 1e-5f, stream));
   }
+  CHECK(wait_ready(m->dec_ready, stream));
   CHECK(gpt_decode_tokens(dt, m->n_out_tok, ws->hf, T, m->dec_w, m->dec_n, m->dec_off, x_prev, out, B, d, m->D, stream));
   return 0;
 }

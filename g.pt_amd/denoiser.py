@@ -328,7 +328,18 @@ class _Engine:
             import numpy as np
             table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dev)
             self.items = (table, len(items), first4)
-        self.keep, self.cmodel = keep, cm
+        self.keep, self.cmodel, self.clayers = keep, cm, layers
+        self._ready = None
+
+    def set_ready(self, layer_events, dec_event):
+        """Operands delivered asynchronously (TrainStep's all-gather of the other ranks' shards): the forward waits for
+        layer_events[l] (torch.cuda.Event or None) before block l's first kernel and for dec_event before the decoder Linears
+        (gpt_layer_t.ready / gpt_model_t.dec_ready).  The events are kept alive here until they are replaced."""
+        assert len(layer_events) == self.model.decoder.n_layer
+        for ly, ev in zip(self.clayers, layer_events):
+            ly.ready = ev.cuda_event if ev is not None else None
+        self.cmodel.dec_ready = dec_event.cuda_event if dec_event is not None else None
+        self._ready = (list(layer_events), dec_event)
 
     # ---- activations
     def workspace(self, B, keep_activations=False):

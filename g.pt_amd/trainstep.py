@@ -149,6 +149,7 @@ class TrainStep:
             self.g16 = torch.zeros(self.arena.s_end, dtype=torch.bfloat16, device=dev)
             self.gshard16 = torch.zeros(self.n_own, dtype=torch.bfloat16, device=dev)
         self._params_stale = self._ema_stale = False
+        self._gather_events = self._operands_done = None
         self.model.register_state_dict_pre_hook(lambda *a, **k: self.sync_params())
         if self.ema is not None:
             self.ema.register_state_dict_pre_hook(lambda *a, **k: self.sync_ema())
@@ -167,15 +168,55 @@ class TrainStep:
 
     def _gather(self, buf, stale_attr):
         """All-gathers every S bucket of an arena-shaped buffer in place from the ranks' own chunks."""
+        self._wait_operands()
         hs = [dp.all_gather_into(buf[lo:hi], buf[own:own + c]) for lo, hi, c, own, _ in self.s_chunks]
         dp.wait_all(hs)
         setattr(self, stale_attr, False)
 
+    def _gather_operands(self, buf):
+        """The all-gather of the updated operands, OFF the compute stream: the buckets are gathered in forward order (block 0
+        first, the decoder Linears last) on the side stream, each followed by an event, and the engine's forward waits for a
+        block's event right before that block (gpt_layer_t.ready) - the next step's q_sample, encoder and first blocks run
+        while the later buckets are still on the wire.  GPT_DP_GATHER_OVERLAP=0: the compute stream waits for all of them here."""
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side, ar, Lr = self._side, self.arena, self.model.decoder.n_layer
+        if self._gather_events is None:
+            self._gather_events = [torch.cuda.Event() for _ in self.s_chunks]
+        side.wait_stream(main)                       # the optimizer pass that wrote the own chunks
+        layer_ev, dec_ev = [None] * Lr, None
+        with torch.cuda.stream(side):
+            for (lo, hi, c, own, _), ev in sorted(zip(self.s_chunks, self._gather_events), key=lambda z: z[0][0]):
+                h = dp.all_gather_into(buf[lo:hi], buf[own:own + c])
+                if h is not None:
+                    h.wait()                         # the side stream, not the compute stream, waits for the collective
+                ev.record(side)
+                for l in range(Lr):
+                    if lo <= ar.s_layer_start[l] < hi:
+                        layer_ev[l] = ev
+                if lo <= ar.s_dec_start < hi:
+                    dec_ev = ev
+        self._operands_done = side.record_event()
+        if os.environ.get("GPT_DP_GATHER_OVERLAP", "1") == "0":      # A/B measurements
+            self._wait_operands()
+            return
+        self.eng.set_ready(layer_ev, dec_ev)
+
+    def _wait_operands(self):
+        """Makes the compute stream wait for an operand all-gather still in flight (anything but the engine's forward that
+        touches the parameters or their operand copies: the lazy fp32 gathers, state_dict())."""
+        if getattr(self, "_operands_done", None) is not None:
+            torch.cuda.current_stream().wait_event(self._operands_done)
+            self._operands_done = None
+
     @torch.no_grad()
     def sync_params(self):
         """fp32 parameters of the other ranks' shards (bf16 compute mode gathers only the bf16 operands per step)."""
-        if self.shard and self._params_stale:
-            self._gather(self.flat.params, "_params_stale")
+        if self.shard:
+            self._wait_operands()
+            if self._params_stale:
+                self._gather(self.flat.params, "_params_stale")
 
     @torch.no_grad()
     def sync_ema(self):
@@ -307,10 +348,11 @@ class TrainStep:
                 self.grads.zero_()
             # the updated operands of every rank's shard: bf16 copies in bf16 compute mode (half the bytes), else the fp32 parameters
             if self.code == L.BF16:
-                self._gather(packed, "_params_stale")
+                self._gather_operands(packed)
                 self._params_stale = True      # the fp32 parameters of the other shards follow on demand (sync_params)
             else:
-                self._gather(self.flat.params, "_params_stale")
+                self._gather_operands(self.flat.params)
+                self._params_stale = False
             self._ema_stale = ema is not None
         # the step wrote the parameters and this engine's packed operands together, behind torch's back (the EMA copy's own
         # engines re-derive their operands on every use: denoiser.py _Engine.refresh)
@@ -318,6 +360,8 @@ class TrainStep:
         # transposed dgrad operands of the new weights: needed by the NEXT backward only, so the 48 transposes run on a side
         # stream beside the next forward (memory-bound beside MFMA-bound; 0.9 ms of an 18 ms step at B = 128 otherwise)
         if os.environ.get("GPT_TRAIN_SIDE_STREAM", "1") == "0":      # A/B measurements
+            if self.shard:
+                self._wait_operands()
             _ensure_training_state(self.eng)
             return
         main = torch.cuda.current_stream()

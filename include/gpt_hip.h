@@ -281,6 +281,10 @@ typedef struct {
   const void* wproj; const float* bproj;   /* [d, d]   */
   const void* w1;    const float* b1;      /* [4d, d]  */
   const void* w2;    const float* b2;      /* [d, 4d]  */
+  /* hipEvent_t or NULL.  Non-NULL: the forward makes its stream wait for this event before the layer's first kernel - the
+   * layer's operands are being delivered asynchronously (the sharded optimizer step all-gathers them on another stream while
+   * the next forward already runs its first layers: g.pt_amd/trainstep.py).  The event must have been recorded. */
+  const void* ready;
 } gpt_layer_t;
 
 typedef struct {
@@ -294,6 +298,7 @@ typedef struct {
   const void* dec_w[GPT_MAX_TOKENS];       /* (dtype) [dec_n, d] */
   int dec_n[GPT_MAX_TOKENS], dec_off[GPT_MAX_TOKENS];
   const gpt_layer_t* layers;               /* host array [n_layer] */
+  const void* dec_ready;                   /* hipEvent_t or NULL: as gpt_layer_t.ready, for the decoder Linears (dec_w) */
 } gpt_model_t;
 
 /* Activations.  With layer_stride == 0 every layer reuses the same buffers (inference); with

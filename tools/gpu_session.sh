@@ -1,13 +1,10 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 900 python -u -m pytest tests/test_hip_parity.py -x -q -m gpu --timeout 120 --timeout-method thread > gpurun_out/g128_parity.log 2>&1; rc=$?; tail -3 gpurun_out/g128_parity.log | cut -c1-200
-if grep -q "HSA_STATUS_ERROR\|Memory access fault" gpurun_out/g128_parity.log; then echo FAULT; exit 1; fi
+timeout -k 10 900 python -u -m pytest tests/test_hip_training.py -x -q -m gpu --timeout 300 --timeout-method thread > gpurun_out/ag_train.log 2>&1; rc=$?; tail -5 gpurun_out/ag_train.log | cut -c1-300
+if grep -q "HSA_STATUS_ERROR\|Memory access fault" gpurun_out/ag_train.log; then echo FAULT; exit 1; fi
 [ $rc -eq 0 ] || exit $rc
+export GPT_DP_REHEARSE=1
 for v in 0 1 0 1; do
-echo "== GPT_GEMM_128=$v"
-GPT_GEMM_128=$v timeout -k 10 200 python tools/gemm_bench.py --rounds 30 --batch 64 2>&1 | grep -v amdgpu.ids | cut -c1-150 || exit 1
-done
-for v in 0 1; do
-echo "== bench B=64 GPT_GEMM_128=$v"
-GPT_GEMM_128=$v timeout -k 10 300 python bench.py --batch 64 --steps 100 --warmup 10 --no-cpu-baseline --no-extra --repeats 3 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'])" || exit 1
+echo "== GPT_DP_GATHER_OVERLAP=$v"
+GPT_DP_GATHER_OVERLAP=$v timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 2951$v bench.py --gpus 1 --mode train --batch 128 --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('final_loss'))" || exit 1
 done
