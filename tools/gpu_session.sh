@@ -1,10 +1,17 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 900 python -u -m pytest tests/test_hip_training.py -x -q -m gpu --timeout 300 --timeout-method thread > gpurun_out/ag_train.log 2>&1; rc=$?; tail -5 gpurun_out/ag_train.log | cut -c1-300
-if grep -q "HSA_STATUS_ERROR\|Memory access fault" gpurun_out/ag_train.log; then echo FAULT; exit 1; fi
+timeout -k 10 1500 python -u -m pytest tests -x -q -m gpu --timeout 300 --timeout-method thread > gpurun_out/r2_gpu_all.log 2>&1; rc=$?; tail -4 gpurun_out/r2_gpu_all.log | cut -c1-300
+if grep -q "HSA_STATUS_ERROR\|Memory access fault" gpurun_out/r2_gpu_all.log; then echo FAULT; exit 1; fi
 [ $rc -eq 0 ] || exit $rc
-export GPT_DP_REHEARSE=1
-for v in 0 1 0 1; do
-echo "== GPT_DP_GATHER_OVERLAP=$v"
-GPT_DP_GATHER_OVERLAP=$v timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 2951$v bench.py --gpus 1 --mode train --batch 128 --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('final_loss'))" || exit 1
-done
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1 || { tail -5 gpurun_out/smoke.log; exit 1; }
+tail -2 gpurun_out/smoke.log
+timeout -k 10 900 python bench.py > gpurun_out/r2_bench2.json 2> gpurun_out/r2_bench2.err || { tail -5 gpurun_out/r2_bench2.err; exit 1; }
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r2_bench2.json').read().strip().splitlines()[-1])
+print({k:d[k] for k in ('metric','value','ms_per_step','n_gpus','steps')})
+print('roofline',d['roofline']); print('cpu',d['cpu_baseline']); print('spread',d.get('spread'))
+for k in ('fp32','cifar','train','train_weak'):
+    o=d.get(k); 
+    if o: print(k,{kk:o[kk] for kk in o if kk in ('value','unit','ms_per_step','roofline','error')})
+PY
