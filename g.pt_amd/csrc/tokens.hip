@@ -6,6 +6,8 @@
 // The encoder reads its four sources (x, x_prev, scalar tokens) in place, so the (B, 16948)
 // concatenation of :458-459 is never materialised.
 #include "common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 // The reference rounds every product and sum separately (separate ATen kernels); hipcc contracts a*b+c into an
 // FMA by default, __fmul_rn/__fadd_rn included, which changes last bits.  Keep IEEE op-by-op rounding in this file.
@@ -53,14 +55,18 @@ __global__ void scalar_tokens_kernel(const int64_t* __restrict__ t, const void* 
 
 // ------------------------------------------------------------------------------------------ ragged GEMMs
 // Workgroup tile: 64 batch rows x 128 output columns of ONE token; 4 waves as 2 x 2, each 32 x 64
-// (1 x 2 MFMA 32x32 tiles).  K is walked in chunks of 32 elements through a single LDS buffer; ragged K
-// (10, 100, 257, 840, 1000 ...) is zero-filled in LDS, never in memory on the activation side.
+// (1 x 2 MFMA 32x32 tiles).  K is walked in chunks of KC elements through a single LDS buffer, the next chunk's global loads
+// in flight (register staging) during the MFMAs of the current one; ragged K (10, 100, 257, 840, 1000 ...) is zero-filled in
+// LDS, never in memory on the activation side.  KC = 128 for bf16 (32 for fp32, whose chunk is twice the bytes): every chunk
+// costs one exposed memory latency, so r01's 32-element chunks (4 MFMAs per wave between two latencies) made these kernels
+// latency-bound: 61 / 48 us per sampling step at B = 320 for ~100 MB of traffic (r02: see DESIGN.md section 4).
 constexpr int MAX_TOK = 40;
-constexpr int TB = 64, TN = 128, KC = 32;
+constexpr int TB = 64, TN = 128;
+constexpr int KC_PAD = 32;          // the host pads encoder weight rows to a multiple of this (denoiser.py)
 
 struct EncTok {
   const float* src;   // fp32 [B, >=k], row stride src_ld
-  const void* w;      // T [d, w_ld], zero padded to a multiple of KC
+  const void* w;      // T [d, w_ld], zero padded to a multiple of KC_PAD
   int64_t src_ld, w_ld;
   int k;
   int slot;           // output token index
@@ -83,18 +89,18 @@ struct DecArgs {
   int n_tok, T, B, d, D;
 };
 
-template <typename T>
+template <typename T, int KC>
 struct Pitch {
-  static constexpr int value = KC * sizeof(T) + 16;  // bytes per LDS row: 80 (bf16) / 144 (fp32): odd number of 16-B slots
+  static constexpr int value = KC * sizeof(T) + 16;  // bytes per LDS row: 272 (bf16, KC 128) / 80 (bf16, 32) / 144 (fp32, 32)
 };
 
-template <typename T>
+template <typename T, int KC>
 __device__ __forceinline__ void mma_chunk(const char* ldsA, const char* ldsW, int wr, int wc, int lane, f32x16 (&acc)[2]) {
-  constexpr int P = Pitch<T>::value;
+  constexpr int P = Pitch<T, KC>::value;
   const int r = lane & 31, hh = lane >> 5;
   if constexpr (sizeof(T) == 2) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < KC / 16; ++s) {
       const bf16x8 a = *reinterpret_cast<const bf16x8*>(ldsA + (wr * 32 + r) * P + (s * 16 + hh * 8) * 2);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -104,7 +110,7 @@ __device__ __forceinline__ void mma_chunk(const char* ldsA, const char* ldsW, in
     }
   } else {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < KC / 8; ++q) {
       const float4 a = *reinterpret_cast<const float4*>(ldsA + (wr * 32 + r) * P + (q * 8 + hh * 4) * 4);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -118,36 +124,48 @@ __device__ __forceinline__ void mma_chunk(const char* ldsA, const char* ldsW, in
   }
 }
 
-// a [128 rows x KC] weight chunk (T, 16-byte aligned rows) = NW 16-byte vectors per thread; rows >= nrows are clamped
-// (dropped at store).  Split into a register load and an LDS store so that the global loads of chunk t+1 fly during
-// the MFMAs of chunk t (single LDS buffer, register staging).
-template <typename T>
-struct WStage {
-  static constexpr int V = KC * sizeof(T) / 16;   // 16-byte vectors per row: 4 (bf16) / 8 (fp32)
-  static constexpr int NW = TN * V / 256;         // per thread: 2 (bf16) / 4 (fp32)
-  u32x4 v[NW];
-  __device__ __forceinline__ void load(const T* w, int64_t ld, int row0, int nrows, int k0, int tid) {
+// a [ROWS x KC] chunk of a row-major T matrix (16-byte aligned rows) = NV 16-byte vectors per thread; rows >= nrows are clamped
+// (dropped at store), vectors starting at or beyond column kmax (a multiple of the vector width) are zero.  Split into a register
+// load and an LDS store so that the global loads of chunk t+1 fly during the MFMAs of chunk t (single LDS buffer).
+// BOUND = false: every vector lies inside the rows (kmax is ignored: no clamp, no zeroing)
+template <typename T, int KC, int ROWS, bool BOUND = true>
+struct Stage {
+  static constexpr int V = KC * sizeof(T) / 16;   // 16-byte vectors per row
+  static constexpr int NV = ROWS * V / 256;       // per thread
+  static constexpr int EPV = 16 / sizeof(T);      // elements per vector
+  u32x4 v[NV];
+  int k0, kmax;
+  // Nothing here may CONSUME a loaded value (the zeroing of out-of-range vectors happens in store()), and no branch may
+  // surround a load (clamped address instead): either makes hipcc wait for the loads inside the chunk that issued them.
+  __device__ __forceinline__ void load(const T* base, int64_t ld, int row0, int nrows, int k0_, int kmax_, int tid) {
+    k0 = k0_;
+    kmax = kmax_;
 #pragma unroll
-    for (int j = 0; j < NW; ++j) {
+    for (int j = 0; j < NV; ++j) {
       const int i = tid + j * 256, row = i / V, c = i % V;
       int gr = row0 + row;
       gr = gr < nrows ? gr : nrows - 1;
-      v[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(w + (int64_t)gr * ld + k0) + c * 16);
+      const int k = k0 + c * EPV;
+      v[j] = *reinterpret_cast<const u32x4*>(base + (int64_t)gr * ld + (!BOUND || k < kmax ? k : 0));
     }
   }
   __device__ __forceinline__ void store(char* lds, int tid) const {
-    constexpr int P = Pitch<T>::value;
+    constexpr int P = Pitch<T, KC>::value;
+    __builtin_amdgcn_sched_barrier(0);    // the zeroing selects below consume the loads: they must not be scheduled into the chunk before
 #pragma unroll
-    for (int j = 0; j < NW; ++j) {
+    for (int j = 0; j < NV; ++j) {
       const int i = tid + j * 256, row = i / V, c = i % V;
-      *reinterpret_cast<u32x4*>(lds + row * P + c * 16) = v[j];
+      const bool ok = !BOUND || k0 + c * EPV < kmax;
+      u32x4 t = v[j];
+      t.x = ok ? t.x : 0u; t.y = ok ? t.y : 0u; t.z = ok ? t.z : 0u; t.w = ok ? t.w : 0u;
+      *reinterpret_cast<u32x4*>(lds + row * P + c * 16) = t;
     }
   }
 };
 
-template <typename T>
+template <typename T, int KC>
 __global__ __launch_bounds__(256) void encode_kernel(EncArgs g) {
-  constexpr int P = Pitch<T>::value;
+  constexpr int P = Pitch<T, KC>::value;
   __shared__ __attribute__((aligned(16))) char smem[(TB + TN) * P];
   char* ldsA = smem;
   char* ldsW = smem + TB * P;
@@ -161,33 +179,102 @@ __global__ __launch_bounds__(256) void encode_kernel(EncArgs g) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
-  const int arow = tid >> 2, acol = (tid & 3) * 8;   // 64 rows x 4 threads x 8 consecutive k
+  // activations: 64 rows x 4 threads; a thread holds groups of 8 consecutive k, 32 apart (the 4 threads of a row read 128
+  // contiguous bytes per group).  The sources are fp32 rows inside x / x_prev / the scalar tokens: 16-byte aligned for the big
+  // MNIST tokens, 8 for the CIFAR-10 ones (D = 5370), 4 for the 257-wide scalar tokens -> the widest load the token allows
+  // (workgroup-uniform choice): one dword per lane and instruction costs the vector-memory path as much as four.
+  constexpr int NG = KC / 32;
+  const int arow = tid >> 2, acol = (tid & 3) * 8;
   const int gb = b0 + arow;
   const float* srow = tk.src + (int64_t)(gb < g.B ? gb : g.B - 1) * tk.src_ld;
-  float av[8];
-  WStage<T> ws;
-  auto load_a = [&](int k0) {
+  const int avec = (((uintptr_t)tk.src % 16) == 0 && tk.src_ld % 4 == 0 && tk.k % 4 == 0) ? 4
+                   : (((uintptr_t)tk.src % 8) == 0 && tk.src_ld % 2 == 0 && tk.k % 2 == 0) ? 2 : 1;
+  struct AStage {
+    float v[NG][8];
+    int k0;
+  };
+  const int kw = (int)tk.w_ld;                     // weight rows are valid (zero padded) up to w_ld
+  const int nchunk = (tk.k + KC - 1) / KC, last = nchunk - 1;
+  // the whole K loop once per load width (no branch on it inside the loop)
+  auto run = [&](auto avec_c) {
+    constexpr int AVEC = decltype(avec_c)::value;
+    // loads only (clamped addresses); out-of-range elements are zeroed in store_a
+    auto load_a = [&](AStage& st, int k0) {
+      st.k0 = k0;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int k = k0 + acol + e;
-      av[e] = k < tk.k ? srow[k] : 0.f;
+      for (int q = 0; q < NG; ++q) {
+        const int kq = k0 + q * 32 + acol;
+#pragma unroll
+        for (int h = 0; h < 8 / AVEC; ++h) {
+          const int k = kq + AVEC * h;             // k % AVEC == 0 and tk.k % AVEC == 0: a vector is all inside or all outside
+          const float* p = srow + (k < tk.k ? k : 0);
+          if constexpr (AVEC == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(p);
+            st.v[q][4 * h] = t.x; st.v[q][4 * h + 1] = t.y; st.v[q][4 * h + 2] = t.z; st.v[q][4 * h + 3] = t.w;
+          } else if constexpr (AVEC == 2) {
+            const float2 t = *reinterpret_cast<const float2*>(p);
+            st.v[q][2 * h] = t.x; st.v[q][2 * h + 1] = t.y;
+          } else {
+            st.v[q][h] = *p;
+          }
+        }
+      }
+    };
+    auto store_a = [&](const AStage& st) {
+      __builtin_amdgcn_sched_barrier(0);  // as in Stage::store
+#pragma unroll
+      for (int q = 0; q < NG; ++q) {
+        float e[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = st.k0 + q * 32 + acol + i < tk.k ? st.v[q][i] : 0.f;
+        char* dst = ldsA + arow * P + (q * 32 + acol) * sizeof(T);
+        if constexpr (sizeof(T) == 2) {
+          u32x4 pk;
+          pk.x = pack_bf16x2(e[0], e[1]); pk.y = pack_bf16x2(e[2], e[3]);
+          pk.z = pack_bf16x2(e[4], e[5]); pk.w = pack_bf16x2(e[6], e[7]);
+          *reinterpret_cast<u32x4*>(dst) = pk;
+        } else {
+          reinterpret_cast<float4*>(dst)[0] = make_float4(e[0], e[1], e[2], e[3]);
+          reinterpret_cast<float4*>(dst)[1] = make_float4(e[4], e[5], e[6], e[7]);
+        }
+      }
+    };
+    // two register stages: the loads of chunk c + 2 are issued before the MFMAs of chunk c (one chunk ahead left a whole
+    // memory latency exposed per chunk).  Past the last chunk the last one is simply loaded again: no branch around a load.
+    AStage a0, a1;
+    Stage<T, KC, TN> w0, w1;
+    load_a(a0, 0);
+    w0.load((const T*)tk.w, tk.w_ld, n0, g.d, 0, kw, tid);
+    load_a(a1, min(1, last) * KC);
+    w1.load((const T*)tk.w, tk.w_ld, n0, g.d, min(1, last) * KC, kw, tid);
+    // (pairs of chunks, then the odd one: a `break` between the halves would enter the loop header with the two stages'
+    // loads in the other order, and the wait insertion would again assume the worst)
+    for (int c = 0; c + 1 < nchunk; c += 2) {
+      store_a(a0);
+      w0.store(ldsW, tid);
+      __syncthreads();
+      load_a(a0, min(c + 2, last) * KC);
+      w0.load((const T*)tk.w, tk.w_ld, n0, g.d, min(c + 2, last) * KC, kw, tid);
+      mma_chunk<T, KC>(ldsA, ldsW, wr, wc, lane, acc);
+      __syncthreads();
+      store_a(a1);
+      w1.store(ldsW, tid);
+      __syncthreads();
+      load_a(a1, min(c + 3, last) * KC);
+      w1.load((const T*)tk.w, tk.w_ld, n0, g.d, min(c + 3, last) * KC, kw, tid);
+      mma_chunk<T, KC>(ldsA, ldsW, wr, wc, lane, acc);
+      __syncthreads();
+    }
+    if (nchunk & 1) {                               // stage 0 holds the last chunk
+      store_a(a0);
+      w0.store(ldsW, tid);
+      __syncthreads();
+      mma_chunk<T, KC>(ldsA, ldsW, wr, wc, lane, acc);
     }
   };
-  load_a(0);
-  ws.load((const T*)tk.w, tk.w_ld, n0, g.d, 0, tid);
-  for (int k0 = 0; k0 < tk.k; k0 += KC) {
-    T* dst = reinterpret_cast<T*>(ldsA + arow * P) + acol;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) elem<T>::store(dst + e, av[e]);
-    ws.store(ldsW, tid);
-    __syncthreads();
-    if (k0 + KC < tk.k) {
-      load_a(k0 + KC);
-      ws.load((const T*)tk.w, tk.w_ld, n0, g.d, k0 + KC, tid);
-    }
-    mma_chunk<T>(ldsA, ldsW, wr, wc, lane, acc);
-    __syncthreads();
-  }
+  if (avec == 4) run(std::integral_constant<int, 4>{});
+  else if (avec == 2) run(std::integral_constant<int, 2>{});
+  else run(std::integral_constant<int, 1>{});
   const int r = lane & 31, hh = lane >> 5;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -201,9 +288,10 @@ __global__ __launch_bounds__(256) void encode_kernel(EncArgs g) {
   }
 }
 
-template <typename T>
+// d % KC == 0 (host)
+template <typename T, int KC>
 __global__ __launch_bounds__(256) void decode_kernel(DecArgs g) {
-  constexpr int P = Pitch<T>::value;
+  constexpr int P = Pitch<T, KC>::value;
   __shared__ __attribute__((aligned(16))) char smem[(TB + TN) * P];
   char* ldsA = smem;
   char* ldsW = smem + TB * P;
@@ -219,36 +307,38 @@ __global__ __launch_bounds__(256) void decode_kernel(DecArgs g) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
-  constexpr int V = KC * sizeof(T) / 16;
-  constexpr int NA = TB * V / 256;                 // feature vectors per thread: 1 (bf16) / 2 (fp32)
-  const T* feat = (const T*)g.feat;
-  u32x4 fv[NA];
-  WStage<T> ws;
-  auto load_f = [&](int k0) {
-#pragma unroll
-    for (int j = 0; j < NA; ++j) {
-      const int i = tid + j * 256, row = i / V, c = i % V;
-      int gb = b0 + row;
-      gb = gb < g.B ? gb : g.B - 1;
-      fv[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(feat + ((int64_t)gb * g.T + blockIdx.z) * g.d + k0) + c * 16);
-    }
-  };
-  load_f(0);
-  ws.load((const T*)tk.w, g.d, n0, tk.n, 0, tid);
-  for (int k0 = 0; k0 < g.d; k0 += KC) {
-#pragma unroll
-    for (int j = 0; j < NA; ++j) {
-      const int i = tid + j * 256, row = i / V, c = i % V;
-      *reinterpret_cast<u32x4*>(ldsA + row * P + c * 16) = fv[j];
-    }
-    ws.store(ldsW, tid);
+  // features of this token: rows b of feat[B, T, d] = a matrix of row stride T * d starting at token * d
+  const T* feat = (const T*)g.feat + (int64_t)blockIdx.z * g.d;
+  const int64_t fld = (int64_t)g.T * g.d;
+  Stage<T, KC, TB, false> f0, f1;
+  Stage<T, KC, TN, false> w0, w1;
+  const int nchunk = g.d / KC;
+  const int last = nchunk - 1;               // no branch around any load (see encode_kernel)
+  f0.load(feat, fld, b0, g.B, 0, g.d, tid);
+  w0.load((const T*)tk.w, g.d, n0, tk.n, 0, g.d, tid);
+  f1.load(feat, fld, b0, g.B, min(1, last) * KC, g.d, tid);
+  w1.load((const T*)tk.w, g.d, n0, tk.n, min(1, last) * KC, g.d, tid);
+  for (int c = 0; c + 1 < nchunk; c += 2) {  // two register stages, pairs of chunks then the odd one, as in encode_kernel
+    f0.store(ldsA, tid);
+    w0.store(ldsW, tid);
     __syncthreads();
-    if (k0 + KC < g.d) {
-      load_f(k0 + KC);
-      ws.load((const T*)tk.w, g.d, n0, tk.n, k0 + KC, tid);
-    }
-    mma_chunk<T>(ldsA, ldsW, wr, wc, lane, acc);
+    f0.load(feat, fld, b0, g.B, min(c + 2, last) * KC, g.d, tid);
+    w0.load((const T*)tk.w, g.d, n0, tk.n, min(c + 2, last) * KC, g.d, tid);
+    mma_chunk<T, KC>(ldsA, ldsW, wr, wc, lane, acc);
     __syncthreads();
+    f1.store(ldsA, tid);
+    w1.store(ldsW, tid);
+    __syncthreads();
+    f1.load(feat, fld, b0, g.B, min(c + 3, last) * KC, g.d, tid);
+    w1.load((const T*)tk.w, g.d, n0, tk.n, min(c + 3, last) * KC, g.d, tid);
+    mma_chunk<T, KC>(ldsA, ldsW, wr, wc, lane, acc);
+    __syncthreads();
+  }
+  if (nchunk & 1) {
+    f0.store(ldsA, tid);
+    w0.store(ldsW, tid);
+    __syncthreads();
+    mma_chunk<T, KC>(ldsA, ldsW, wr, wc, lane, acc);
   }
   const int r = lane & 31, hh = lane >> 5;
 #pragma unroll
@@ -289,9 +379,9 @@ extern "C" int gpt_encode_tokens_subset(int dtype, int n_sel, const float* const
   EncArgs g;
   for (int i = 0; i < n_sel; ++i) {
     GPT_REQUIRE(host_src[i] && host_w[i] && host_k[i] > 0, "gpt_encode_tokens: token %d: null/empty", i);
-    const int kp = (host_k[i] + KC - 1) / KC * KC;
+    const int kp = (host_k[i] + KC_PAD - 1) / KC_PAD * KC_PAD;
     GPT_REQUIRE(host_w_ld[i] >= kp && (host_w_ld[i] * esz) % 16 == 0 && ((uintptr_t)host_w[i] % 16) == 0,
-                "gpt_encode_tokens: token %d: weight rows must be zero-padded to a multiple of %d and 16-byte aligned", i, KC);
+                "gpt_encode_tokens: token %d: weight rows must be zero-padded to a multiple of %d and 16-byte aligned", i, KC_PAD);
     GPT_REQUIRE(host_src_ld[i] >= host_k[i], "gpt_encode_tokens: token %d: src_ld < k", i);
     const int slot = host_slot ? host_slot[i] : i;
     GPT_REQUIRE(slot >= 0 && slot < n_tok, "gpt_encode_tokens: token %d: output slot %d out of range", i, slot);
@@ -299,8 +389,10 @@ extern "C" int gpt_encode_tokens_subset(int dtype, int n_sel, const float* const
   }
   g.out = out; g.n_tok = n_tok; g.B = B; g.d = d;
   const dim3 grid((d + TN - 1) / TN, (B + TB - 1) / TB, n_sel), block(256);
-  if (dtype == GPT_BF16) hipLaunchKernelGGL(encode_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, g);
-  else hipLaunchKernelGGL(encode_kernel<float>, grid, block, 0, (hipStream_t)stream, g);
+  static const bool wide = [] { const char* e = getenv("GPT_TOKENS_KC128"); return !e || atoi(e) != 0; }();   // 0: r01's chunks (A/B)
+  if (dtype == GPT_BF16 && wide) hipLaunchKernelGGL((encode_kernel<bf16_t, 128>), grid, block, 0, (hipStream_t)stream, g);
+  else if (dtype == GPT_BF16) hipLaunchKernelGGL((encode_kernel<bf16_t, 32>), grid, block, 0, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL((encode_kernel<float, 32>), grid, block, 0, (hipStream_t)stream, g);
   return gpt_launch_status("gpt_encode_tokens");
 }
 
@@ -315,7 +407,7 @@ extern "C" int gpt_decode_tokens(int dtype, int n_tok, const void* feat, int T, 
                                  int D, void* stream) {
   GPT_REQUIRE(dtype == GPT_F32 || dtype == GPT_BF16, "gpt_decode_tokens: bad dtype %d", dtype);
   GPT_REQUIRE(n_tok > 0 && n_tok <= MAX_TOK && n_tok <= T, "gpt_decode_tokens: n_tok=%d out of range", n_tok);
-  GPT_REQUIRE(B > 0 && d > 0 && d % KC == 0 && D > 0 && feat && out, "gpt_decode_tokens: bad sizes (d must be a multiple of %d)", KC);
+  GPT_REQUIRE(B > 0 && d > 0 && d % 32 == 0 && D > 0 && feat && out, "gpt_decode_tokens: bad sizes (d must be a multiple of 32)");
   GPT_REQUIRE(((uintptr_t)feat % 16) == 0, "gpt_decode_tokens: feat must be 16-byte aligned");
   DecArgs g;
   int max_n = 0;
@@ -328,7 +420,9 @@ extern "C" int gpt_decode_tokens(int dtype, int n_tok, const void* feat, int T, 
   }
   g.feat = feat; g.resid = resid; g.out = out; g.n_tok = n_tok; g.T = T; g.B = B; g.d = d; g.D = D;
   const dim3 grid((max_n + TN - 1) / TN, (B + TB - 1) / TB, n_tok), block(256);
-  if (dtype == GPT_BF16) hipLaunchKernelGGL(decode_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, g);
-  else hipLaunchKernelGGL(decode_kernel<float>, grid, block, 0, (hipStream_t)stream, g);
+  static const bool wide = [] { const char* e = getenv("GPT_TOKENS_KC128"); return !e || atoi(e) != 0; }();
+  if (dtype == GPT_BF16 && wide && d % 128 == 0) hipLaunchKernelGGL((decode_kernel<bf16_t, 128>), grid, block, 0, (hipStream_t)stream, g);
+  else if (dtype == GPT_BF16) hipLaunchKernelGGL((decode_kernel<bf16_t, 32>), grid, block, 0, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL((decode_kernel<float, 32>), grid, block, 0, (hipStream_t)stream, g);
   return gpt_launch_status("gpt_decode_tokens");
 }
