@@ -60,8 +60,15 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const DyT
   for (int row = row_begin + wave; row < row_end; row += LNB_WAVES) {
     const float mu = mean[row], rs = rstd[row];
     const int64_t base = (int64_t)row * d;
-    f32x4 xh[NCH], dyv[NCH];
+    f32x4 xh[NCH], dyv[NCH], rv[NCH];
     float s1 = 0.f, s2 = 0.f;
+    // all three operands of the row are requested before anything is computed (the residual used to be loaded after the two
+    // wave reductions: a second memory latency per row, and a wave has only one or two rows at the small batches)
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c = ch * 256 + lane * 4;
+      rv[ch] = (resid && c < d) ? load_row4<float>(resid + base + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       const int c = ch * 256 + lane * 4;
@@ -93,7 +100,7 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const DyT
         pb[ch][j] += dyv[ch][j];
       }
       if (c < d) {
-        if (resid) dx += load_row4<float>(resid + base + c);
+        dx += rv[ch];
         store_row4(gout + base + c, dx);
         if (gout_t) store_row4(gout_t + base + c, dx);
         pc[ch] += dx;
