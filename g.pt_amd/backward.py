@@ -116,32 +116,58 @@ def _ensure_training_state(eng):
     eng._t_sig = eng.sig
 
 
-def _scratch(eng, B):
+def _scratch(eng, B, slots=1):
+    """Scratch of the backward; `slots` > 1: the dY operands of deferred weight-gradient launches (gpt_backward_t.wgrad_defer)."""
     have = getattr(eng, "_bw_scratch", None)
-    if have is not None and have[0] >= B:
+    if have is not None and have[0] >= B and have[2] >= slots:
         return have[1]
     dec = eng.model.decoder
     d, T = dec.n_embd, dec.block_size
     M = B * T
     Mp = (M + 63) // 64 * 64
     dev, td = eng.device, eng.tdtype
-    s = dict(g=torch.empty(M, d, dtype=torch.float32, device=dev), gt=torch.empty(M, d, dtype=td, device=dev),
-             d_h=torch.empty(M, d, dtype=td, device=dev), d_qkv=torch.empty(M, 3 * d, dtype=td, device=dev),
-             d_act=torch.empty(M, 4 * d, dtype=td, device=dev), tA=torch.empty(4 * d, Mp, dtype=td, device=dev),
+    s = dict(g=torch.empty(M, d, dtype=torch.float32, device=dev), gt=torch.empty(slots * M, d, dtype=td, device=dev),
+             d_h=torch.empty(M, d, dtype=td, device=dev), d_qkv=torch.empty(slots * M, 3 * d, dtype=td, device=dev),
+             d_act=torch.empty(slots * M, 4 * d, dtype=td, device=dev), tA=torch.empty(4 * d, Mp, dtype=td, device=dev),
              tB=torch.empty(4 * d, Mp, dtype=td, device=dev), d_tok=torch.empty(M, d, dtype=torch.float32, device=dev))
-    eng._bw_scratch = (B, s)
+    eng._bw_scratch = (B, s, slots)
     return s
+
+
+def _grouped_wgrads(eng, B):
+    """True where gpt_denoiser_backward computes the Blocks' weight gradients by the grouped TN launch."""
+    dec = eng.model.decoder
+    return eng.code == L.BF16 and (B * dec.block_size) % 64 == 0 and dec.n_embd % 256 == 0 and \
+        os.environ.get("GPT_WGRAD_TN", "1") != "0"
+
+
+def wgrad_defer_layers(eng, B):
+    """Blocks whose grouped weight-gradient launches are worth merging (gpt_backward_t.wgrad_defer): the smallest G <= 4 that
+    minimises whole rounds of CUs per Block, ceil(G * tiles / CUs) / G, with tiles = 12 (n_embd / 256)^2 per Block (n_embd 1536:
+    432 tiles -> G = 4: 7 rounds per four Blocks instead of 8; n_embd 2048: 768 tiles = 3 rounds exactly -> 1).
+    GPT_WGRAD_DEFER=<G> forces a value (A/B measurements)."""
+    if not _grouped_wgrads(eng, B):
+        return 1
+    forced = os.environ.get("GPT_WGRAD_DEFER")
+    if forced is not None:
+        return max(1, min(4, int(forced)))
+    tiles = 12 * (eng.model.decoder.n_embd // 256) ** 2
+    cus = torch.cuda.get_device_properties(eng.device).multi_processor_count
+    best, best_cost = 1, None
+    for g in range(1, 5):
+        cost = -(-g * tiles // cus) / g
+        if best_cost is None or cost < best_cost - 1e-9:
+            best, best_cost = g, cost
+    return best
 
 
 def can_overwrite_wgrads(eng, B):
     """True where gpt_denoiser_backward computes the Blocks' weight gradients by the grouped TN launch, which can store them
     instead of accumulating (gpt_backward_t.wgrad_overwrite)."""
-    dec = eng.model.decoder
-    return eng.code == L.BF16 and (B * dec.block_size) % 64 == 0 and dec.n_embd % 256 == 0 and \
-        os.environ.get("GPT_WGRAD_TN", "1") != "0" and os.environ.get("GPT_WGRAD_OVERWRITE", "1") != "0"
+    return _grouped_wgrads(eng, B) and os.environ.get("GPT_WGRAD_OVERWRITE", "1") != "0"
 
 
-def _descriptor(eng, buf, scratch, overwrite=False):
+def _descriptor(eng, buf, scratch, overwrite=False, defer=1):
     dec = eng.model.decoder
     ar = eng.arena
     base = buf.data_ptr()
@@ -163,6 +189,7 @@ def _descriptor(eng, buf, scratch, overwrite=False):
     for k, t in scratch.items():
         setattr(bw, k, L.ptr(t))
     bw.wgrad_overwrite = int(overwrite)
+    bw.wgrad_defer = int(defer)
     return bw, layers
 
 
@@ -189,8 +216,11 @@ def backward_into(eng, ws, x, x_prev, d_out, buf, schedule=None, overwrite=False
     each callback is called on the host right after the stages before its stage_end have been enqueued - the hook the
     training step uses to put the gradient all-reduce of finished layers in flight behind them."""
     B = x.shape[0]
-    scratch = _scratch(eng, B)
-    bw, keep = _descriptor(eng, buf, scratch, overwrite)
+    # without a schedule (nothing waits for the gradients of single Blocks) the grouped weight-gradient launches of several
+    # Blocks are merged; with one, every stage range ends with its own launch (the C side merges inside one call only)
+    defer = wgrad_defer_layers(eng, B) if not schedule else 1
+    scratch = _scratch(eng, B, defer)
+    bw, keep = _descriptor(eng, buf, scratch, overwrite, defer)
     n_stages = eng.model.decoder.n_layer + 2
     done = 0
     for stage_end, callback in list(schedule or []) + [(n_stages, None)]:

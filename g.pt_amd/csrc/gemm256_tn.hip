@@ -42,11 +42,11 @@ __device__ __forceinline__ u32x4 tr_frag(const char* base, int kk) {
 // and every workgroup ADDS its partial tile with hardware fp32 atomics (one accumulator register = two full 128-byte
 // lines per wave instruction).  A weight gradient has few output tiles (d x d: 36, d x 4d: 144 on 256 CUs) and a very
 // long contraction (R = B*T rows), so spans fill the chip for the price of the atomics (~0.2 us per partial tile).
-// GROUPED launches: up to 4 independent problems with the same contraction length share one grid (workgroups [off[p], off[p+1])
+// GROUPED launches: up to 16 independent problems (the four weight gradients of up to four Blocks) with the same contraction length share one grid (workgroups [off[p], off[p+1])
 // belong to problem p).  The four weight gradients of a Block (qkv, proj, mlp.0, mlp.2) have 108 + 36 + 144 + 144 = 432 tiles at
 // d = 1536: launched one by one each leaves CUs idle (144 tiles on 256 CUs) or pays atomics for spans; together they are two
 // nearly full rounds of whole contractions, no atomics (B = 128: 4 x 85 us -> see DESIGN.md).
-constexpr int TN_MAX_GROUP = 4;
+constexpr int TN_MAX_GROUP = 16;
 struct TnGroup {
   GemmArgs<bf16_t> g[TN_MAX_GROUP];
   int off[TN_MAX_GROUP + 1];
@@ -64,9 +64,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(TnGroup grp) {
   // this workgroup's problem (workgroup-uniform selects: no dynamic indexing of the kernel argument)
   GemmArgs<bf16_t> g = grp.g[0];
   int wg0 = 0;
-  if (grp.n > 1 && (int)blockIdx.x >= grp.off[1]) { g = grp.g[1]; wg0 = grp.off[1]; }
-  if (grp.n > 2 && (int)blockIdx.x >= grp.off[2]) { g = grp.g[2]; wg0 = grp.off[2]; }
-  if (grp.n > 3 && (int)blockIdx.x >= grp.off[3]) { g = grp.g[3]; wg0 = grp.off[3]; }
+#pragma unroll
+  for (int p = 1; p < TN_MAX_GROUP; ++p)
+    if (p < grp.n && (int)blockIdx.x >= grp.off[p]) { g = grp.g[p]; wg0 = grp.off[p]; }
   const int ksplit = grp.ksplit;
   const int local = (int)blockIdx.x - wg0;
   const int nwg = (g.M / 256) * (g.N / 256), span = local / nwg, bid = local - span * nwg;

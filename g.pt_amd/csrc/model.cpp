@@ -261,49 +261,78 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
   const bool grouped = use_tn && dt == GPT_BF16 && M % 64 == 0 && d % 256 == 0;
   GPT_REQUIRE(!bw->wgrad_overwrite || grouped,
               "gpt_denoiser_backward: wgrad_overwrite needs the grouped TN launch (bf16, B * T %% 64 == 0, n_embd %% 256 == 0)");
+  // Deferred weight gradients (gpt_backward_t.wgrad_defer): Block l works in slot (L - 1 - l) % G of the dY buffers and its four
+  // TN problems wait in `pend` until G Blocks are collected (or the call ends): one grid for all of them.
+  GPT_REQUIRE(bw->wgrad_defer >= 0 && bw->wgrad_defer <= 4, "gpt_denoiser_backward: wgrad_defer %d out of range (0..4)", bw->wgrad_defer);
+  const int G = grouped && bw->wgrad_defer > 1 ? bw->wgrad_defer : 1;
+  auto slot = [&](void* base, int sl, size_t width) { return (void*)((char*)base + (size_t)sl * M * width * es); };
+  struct {
+    const void *P[16], *Q[16];
+    float* C[16];
+    int I[16], J[16];
+    int64_t ldp[16], ldq[16], ldc[16];
+    int n = 0;
+  } pend;
+  auto flush = [&]() -> int {
+    if (pend.n == 0) return 0;
+    const int rc = gpt_gemm_tn_grouped(pend.n, pend.P, pend.ldp, pend.Q, pend.ldq, pend.C, pend.ldc, pend.I, pend.J, M,
+                                       bw->wgrad_overwrite ? 0 : 1, stream);
+    pend.n = 0;
+    return rc;
+  };
   for (int l = L - 1; l >= 0; --l) {
     if (L - l < stage_begin || L - l >= stage_end) continue;
     const gpt_layer_t& ly = m->layers[l];
     const gpt_layer_grad_t& gl = bw->layers[l];
+    const int sl = (L - 1 - l) % G;
+    void* const gt_l = slot(bw->gt, sl, d);                 // dY of this Block's mlp.2 (written by the LayerNorm backward before it)
+    void* const gt_next = slot(bw->gt, (sl + 1) % G, d);    // ... of the Block below
+    void* const d_act_l = slot(bw->d_act, sl, 4 * (size_t)d);
+    void* const d_qkv_l = slot(bw->d_qkv, sl, 3 * (size_t)d);
     const void* h1 = lay(ws->h1, l, d);
     const void* qkv = lay(ws->qkv, l, 3 * (size_t)d);
     const void* att = lay(ws->att, l, d);
     const void* h2 = lay(ws->h2, l, d);
     const void* act = lay(ws->act, l, 4 * (size_t)d);
     void* pre = lay(ws->pre, l, 4 * (size_t)d);
-    void* gt2 = grouped ? bw->tA : bw->gt;               // dY of the attention projection
+    void* gt2 = grouped ? slot(bw->tA, sl, d) : bw->gt;  // dY of the attention projection ([4d, Mp] holds four [M, d] slots)
     // mlp.2
-    if (!fuse_col) CHECK(gpt_colsum(dt, bw->gt, d, gl.g_b2, M, d, stream));
-    if (!grouped) CHECK(wgrad(bw->gt, d, act, 4 * d, gl.g_w2));
-    CHECK(gpt_gemm_nt(dt, bw->gt, d, gl.w2_t, d, nullptr, bw->d_act, 4 * d, pre, 4 * d, M, 4 * d, d, GPT_EPI_DGELU, stream));
+    if (!fuse_col) CHECK(gpt_colsum(dt, gt_l, d, gl.g_b2, M, d, stream));
+    if (!grouped) CHECK(wgrad(gt_l, d, act, 4 * d, gl.g_w2));
+    CHECK(gpt_gemm_nt(dt, gt_l, d, gl.w2_t, d, nullptr, d_act_l, 4 * d, pre, 4 * d, M, 4 * d, d, GPT_EPI_DGELU, stream));
     // mlp.0
-    CHECK(gpt_colsum(dt, bw->d_act, 4 * d, gl.g_b1, M, 4 * d, stream));
-    if (!grouped) CHECK(wgrad(bw->d_act, 4 * d, h2, d, gl.g_w1));
-    CHECK(gpt_gemm_nt(dt, bw->d_act, 4 * d, gl.w1_t, 4 * d, nullptr, bw->d_h, d, nullptr, 0, M, d, 4 * d, GPT_EPI_STORE, stream));
+    CHECK(gpt_colsum(dt, d_act_l, 4 * d, gl.g_b1, M, 4 * d, stream));
+    if (!grouped) CHECK(wgrad(d_act_l, 4 * d, h2, d, gl.g_w1));
+    CHECK(gpt_gemm_nt(dt, d_act_l, 4 * d, gl.w1_t, 4 * d, nullptr, bw->d_h, d, nullptr, 0, M, d, 4 * d, GPT_EPI_STORE, stream));
     CHECK(gpt_layernorm_bwd_colsum(bw->d_h, dt, xbuf(2 * l + 1), stat(2 + 2 * l, 0), stat(2 + 2 * l, 1), ly.ln2_w, bw->g, bw->g, gt2, dt,
                                    gl.g_ln2_w, gl.g_ln2_b, fuse_col ? gl.g_bproj : nullptr, M, d, stream));
     // attention output projection
     if (!fuse_col) CHECK(gpt_colsum(dt, gt2, d, gl.g_bproj, M, d, stream));
     if (!grouped) CHECK(wgrad(gt2, d, att, d, gl.g_wproj));
     CHECK(gpt_gemm_nt(dt, gt2, d, gl.wproj_t, d, nullptr, bw->d_h, d, nullptr, 0, M, d, d, GPT_EPI_STORE, stream));
-    CHECK(gpt_attention_bwd(dt, qkv, bw->d_h, bw->d_qkv, B, T, m->n_head, d / m->n_head, stream));
+    CHECK(gpt_attention_bwd(dt, qkv, bw->d_h, d_qkv_l, B, T, m->n_head, d / m->n_head, stream));
     // query | key | value
-    CHECK(gpt_colsum(dt, bw->d_qkv, 3 * d, gl.g_bqkv, M, 3 * d, stream));
+    CHECK(gpt_colsum(dt, d_qkv_l, 3 * d, gl.g_bqkv, M, 3 * d, stream));
     if (grouped) {
       // mlp.2, mlp.0 first: they are the whole first round (2 x 144 tiles at d = 1536)
-      const void* P[4] = {bw->gt, bw->d_act, bw->d_qkv, gt2};
+      const void* P[4] = {gt_l, d_act_l, d_qkv_l, gt2};
       const void* Q[4] = {act, h2, h1, att};
       float* Cg[4] = {gl.g_w2, gl.g_w1, gl.g_wqkv, gl.g_wproj};
       const int I[4] = {d, 4 * d, 3 * d, d}, J[4] = {4 * d, d, d, d};
-      const int64_t ldp[4] = {d, 4 * d, 3 * d, d}, ldq[4] = {4 * d, d, d, d}, ldc[4] = {4 * d, d, d, d};
-      CHECK(gpt_gemm_tn_grouped(4, P, ldp, Q, ldq, Cg, ldc, I, J, M, bw->wgrad_overwrite ? 0 : 1, stream));
+      for (int k = 0; k < 4; ++k) {
+        const int n = pend.n++;
+        pend.P[n] = P[k]; pend.Q[n] = Q[k]; pend.C[n] = Cg[k]; pend.I[n] = I[k]; pend.J[n] = J[k];
+        pend.ldp[n] = I[k]; pend.ldq[n] = J[k]; pend.ldc[n] = J[k];
+      }
+      if (pend.n == 4 * G) CHECK(flush());
     } else {
-      CHECK(wgrad(bw->d_qkv, 3 * d, h1, d, gl.g_wqkv));
+      CHECK(wgrad(d_qkv_l, 3 * d, h1, d, gl.g_wqkv));
     }
-    CHECK(gpt_gemm_nt(dt, bw->d_qkv, 3 * d, gl.wqkv_t, 3 * d, nullptr, bw->d_h, d, nullptr, 0, M, d, 3 * d, GPT_EPI_STORE, stream));
-    CHECK(gpt_layernorm_bwd_colsum(bw->d_h, dt, xbuf(2 * l), stat(1 + 2 * l, 0), stat(1 + 2 * l, 1), ly.ln1_w, bw->g, bw->g, bw->gt, dt,
+    CHECK(gpt_gemm_nt(dt, d_qkv_l, 3 * d, gl.wqkv_t, 3 * d, nullptr, bw->d_h, d, nullptr, 0, M, d, 3 * d, GPT_EPI_STORE, stream));
+    CHECK(gpt_layernorm_bwd_colsum(bw->d_h, dt, xbuf(2 * l), stat(1 + 2 * l, 0), stat(1 + 2 * l, 1), ly.ln1_w, bw->g, bw->g, gt_next, dt,
                                    gl.g_ln1_w, gl.g_ln1_b, fuse_col && l > 0 ? bw->layers[l - 1].g_b2 : nullptr, M, d, stream));
   }
+  CHECK(flush());                                        // what this call collected (gradients are complete when it returns)
   if (stage_end < L + 2) return 0;
   // stage L + 1 - position embedding: sum over the batch of the gradient of x0 = ln_in(enc) + pos_emb
   CHECK(gpt_colsum(GPT_F32, bw->g, (int64_t)T * d, bw->g_pos_emb, B, T * d, stream));

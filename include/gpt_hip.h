@@ -345,6 +345,11 @@ typedef struct {
    * TN launch computes them (GPT_BF16, B * T % 64 == 0, n_embd % 256 == 0); rejected otherwise.  Every other gradient is
    * accumulated as before. */
   int wgrad_overwrite;
+  /* G = 2..4: the grouped TN launches of up to G consecutive Blocks (inside one gpt_denoiser_backward_stages call) are merged
+   * into one grid, so that their tiles share rounds of CUs (n_embd 1536: 432 tiles per Block = 2 rounds of 256 CUs, 1728 per
+   * four Blocks = 7 rounds instead of 8).  The operands of a deferred launch must survive the Blocks in between: gt, d_act and
+   * d_qkv then hold G slots of [M, d], [M, 4d], [M, 3d] back to back (M = B * T of the call).  0 / 1: one launch per Block. */
+  int wgrad_defer;
 } gpt_backward_t;
 
 /* Backward of gpt_denoiser_forward run on a layer_stride == 1 workspace: d_out[B, D] = dLoss/d(out).

@@ -1,8 +1,10 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 900 python -u -m pytest tests/test_hip_training.py tests/test_hip_fullsize.py -x -q -m gpu --timeout 300 --timeout-method thread > gpurun_out/lnb.log 2>&1; rc=$?; tail -3 gpurun_out/lnb.log | cut -c1-200
-if grep -q "HSA_STATUS_ERROR\|Memory access fault" gpurun_out/lnb.log; then echo FAULT; exit 1; fi
+timeout -k 10 900 python -u -m pytest tests/test_hip_training.py tests/test_hip_fullsize.py tests/test_hip_parity.py -x -q -m gpu --timeout 300 --timeout-method thread > gpurun_out/defer.log 2>&1; rc=$?; tail -3 gpurun_out/defer.log | cut -c1-200
+if grep -q "HSA_STATUS_ERROR\|Memory access fault" gpurun_out/defer.log; then echo FAULT; exit 1; fi
 [ $rc -eq 0 ] || exit $rc
-timeout -k 10 200 python tools/bwd_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-160 || exit 1
-M=26624 timeout -k 10 200 python tools/bwd_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-160 || exit 1
-for i in 1 2; do timeout -k 10 300 python bench.py --mode train --batch 128 --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])" || exit 1; done
+for v in 1 4 1 4; do
+for b in 128 1024; do
+echo "== GPT_WGRAD_DEFER=$v B=$b"
+GPT_WGRAD_DEFER=$v timeout -k 10 300 python bench.py --mode train --batch $b --steps 20 --warmup 4 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('final_loss'))" || exit 1
+done; done
