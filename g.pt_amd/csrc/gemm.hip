@@ -484,7 +484,16 @@ int pick_tail_spans(const GemmArgs<T>& g) {
   return (nk + per - 1) / per;
 }
 
-// cost in units of one full round of 256 x 256 tiles; *m_main = rows given to the 256 x 256 kernel (the rest: ring kernels)
+// tail of a row split: tiles of the 128 x 256 kernel, when they make one reasonably filled round of it (see dispatch)
+template <typename T>
+bool tail_fits128(int tail_m, int N) {
+  static const bool tail128 = [] { const char* e = getenv("GPT_GEMM_TAIL128"); return !e || atoi(e) != 0; }();
+  const int t128 = ((tail_m + 127) / 128) * ((N + 255) / 256);
+  return sizeof(T) == 2 && tail128 && t128 >= n_cus() * 3 / 8 && t128 <= n_cus();
+}
+
+// cost in units of one full round of 256 x 256 tiles; *m_main = rows given to the 256 x 256 kernel (the rest: the 128 x 256
+// kernel where the tail is one round of it - measured 0.58 of a 256-row round at K = 1536 -, else the ring kernels)
 template <typename T>
 double plan_rows256(const GemmArgs<T>& g, int* m_main) {
   static const bool enabled = [] {
@@ -496,12 +505,18 @@ double plan_rows256(const GemmArgs<T>& g, int* m_main) {
   const int rounds = tiles / n_cu, rem = tiles % n_cu;
   *m_main = g.M;
   const double whole = (tiles + n_cu - 1) / n_cu;
-  if (!enabled || rounds == 0 || rem == 0 || rem * 4 > n_cu) return whole;
+  if (!enabled || rounds == 0 || rem == 0) return whole;
   const int main_tiles_m = rounds * n_cu / tn;
   const int mm = main_tiles_m * 256;
   if (mm <= 0 || mm >= g.M) return whole;
-  const int tail128 = ((g.M - mm + 127) / 128) * ((g.N + 127) / 128);
-  const double cost_split = rounds + 0.5 * ((tail128 + 2 * n_cu - 1) / (2 * n_cu)) + 0.08;
+  double cost_split;
+  if (tail_fits128<T>(g.M - mm, g.N)) {
+    cost_split = rounds + 0.58 + 0.04;
+  } else {
+    if (rem * 4 > n_cu) return whole;
+    const int tail128 = ((g.M - mm + 127) / 128) * ((g.N + 127) / 128);
+    cost_split = rounds + 0.5 * ((tail128 + 2 * n_cu - 1) / (2 * n_cu)) + 0.08;
+  }
   if (cost_split < whole) { *m_main = mm; return cost_split; }
   return whole;
 }
@@ -567,6 +582,9 @@ int dispatch(const GemmArgs<T>& g, int epi, hipStream_t s) {
     tail.C = (char*)g.C + (int64_t)m_main * g.ldc * (c32 ? 4 : sizeof(T));
     if (g.aux) tail.aux = (char*)g.aux + (int64_t)m_main * g.ldaux * (aux32 ? 4 : sizeof(T));
     if constexpr (sizeof(T) == 2) {
+      // a tail of several hundred rows (M = 3328, N = 6144: 768 rows) is one well-filled round of the 128 x 256 kernel
+      // (144 tiles) instead of 288 ring-kernel tiles: 35 -> 27 us
+      if (tail_fits128<T>(tail.M, tail.N)) return half_height_bf16(tail, epi, s);
       const int sp = pick_tail_spans(tail);
       if (sp > 1) {
         GemmArgs<T> part = tail;                    // pass 1: raw fp32 partial tiles of the tail rows, [sp][tail.M][N]

@@ -1,10 +1,6 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 900 python -u -m pytest tests/test_hip_training.py tests/test_hip_fullsize.py tests/test_hip_parity.py -x -q -m gpu --timeout 300 --timeout-method thread > gpurun_out/defer.log 2>&1; rc=$?; tail -3 gpurun_out/defer.log | cut -c1-200
-if grep -q "HSA_STATUS_ERROR\|Memory access fault" gpurun_out/defer.log; then echo FAULT; exit 1; fi
-[ $rc -eq 0 ] || exit $rc
-for v in 1 4 1 4; do
-for b in 128 1024; do
-echo "== GPT_WGRAD_DEFER=$v B=$b"
-GPT_WGRAD_DEFER=$v timeout -k 10 300 python bench.py --mode train --batch $b --steps 20 --warmup 4 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('final_loss'))" || exit 1
-done; done
+for v in 0 1 0 1; do
+echo "== GPT_GEMM_TAIL128=$v"
+GPT_GEMM_TAIL128=$v timeout -k 10 200 python tools/gemm_bench.py --rounds 20 --shapes qkv320:8320:4608:1536 fc1_320:8320:6144:1536:1 qkv256:6656:4608:1536 fc1_256:6656:6144:1536:1 qkv512:13312:4608:1536 fc1_512:13312:6144:1536:1 cqkv:33280:6144:2048 cfc1:33280:8192:2048:1 cproj:33280:2048:2048:2 cfc2:33280:2048:8192:2 2>&1 | grep -v amdgpu.ids | cut -c1-110 || exit 1
+done
