@@ -1,6 +1,17 @@
 set -o pipefail
 mkdir -p gpurun_out
-for v in 0 1 0 1; do
-echo "== GPT_GEMM_TAIL128=$v"
-GPT_GEMM_TAIL128=$v timeout -k 10 200 python tools/gemm_bench.py --rounds 20 --shapes qkv320:8320:4608:1536 fc1_320:8320:6144:1536:1 qkv256:6656:4608:1536 fc1_256:6656:6144:1536:1 qkv512:13312:4608:1536 fc1_512:13312:6144:1536:1 cqkv:33280:6144:2048 cfc1:33280:8192:2048:1 cproj:33280:2048:2048:2 cfc2:33280:2048:8192:2 2>&1 | grep -v amdgpu.ids | cut -c1-110 || exit 1
-done
+timeout -k 10 1500 python -u -m pytest tests -x -q -m gpu --timeout 300 --timeout-method thread > gpurun_out/r2_gpu_all.log 2>&1; rc=$?; tail -4 gpurun_out/r2_gpu_all.log | cut -c1-300
+if grep -q "HSA_STATUS_ERROR\|Memory access fault" gpurun_out/r2_gpu_all.log; then echo FAULT; exit 1; fi
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1 || { tail -5 gpurun_out/smoke.log; exit 1; }
+tail -2 gpurun_out/smoke.log
+timeout -k 10 900 python bench.py > gpurun_out/r2_bench3.json 2> gpurun_out/r2_bench3.err || { tail -5 gpurun_out/r2_bench3.err; exit 1; }
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r2_bench3.json').read().strip().splitlines()[-1])
+print({k:d[k] for k in ('metric','value','ms_per_step','n_gpus','steps')})
+print('roofline',{k:d['roofline'][k] for k in ('achieved','frac','traffic','avg_launch_us')}); print('cpu',d['cpu_baseline']['value']); print('spread',d.get('spread'))
+for k in ('fp32','cifar','train','train_weak'):
+    o=d.get(k); 
+    if o: print(k,{kk:(o[kk] if kk!='roofline' else o[kk]['frac']) for kk in o if kk in ('value','ms_per_step','roofline','error')})
+PY
