@@ -49,8 +49,10 @@ def build(case, dtype="fp32", seed=0):
                                    # the 256 x 256 kernel: 224-row tiles with a ragged last row tile (8320 = 37.1 x 224),
                                    # 256-row tiles filling whole rounds, and a row tail handed to the ring kernels
                                    (8320, 1536, 256), (4096, 4096, 128), (8320, 6144, 128),
-                                   # 128-row tiles of the same kernel (few tiles: one per CU)
-                                   (1664, 4608, 192)])
+                                   # 128 x 256 tiles (gemm128.hip: few 256-row tiles, one 128-row tile per CU), also ragged in M and N
+                                   (1664, 4608, 192), (1650, 4600, 192),
+                                   # one round of 256-row tiles + a row tail that is one round of the 128 x 256 kernel
+                                   (3328, 6144, 128), (3300, 6136, 128)])
 def test_gemm_epilogues(dtype, tol, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
     A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
