@@ -301,7 +301,8 @@ def _ddp_rank(rank, world, port, out_path, mode="replicated", dtype="fp32"):
         assert ts.shard == (mode != "replicated")
         for i in range(2):
             batch = _ddp_batch(i)
-            sl = slice(rank * 4, rank * 4 + 4)
+            rows = 8 // world
+            sl = slice(rank * rows, rank * rows + rows)
             ts.step(*(v[sl] for v in batch))
         if ts.shard:
             own = ts.s_chunks[0]
@@ -337,6 +338,16 @@ def test_two_rank_step_equals_full_batch(tmp_path, mode, dtype):
     """2 ranks x 4 rows with the staged, overlapped gradient exchange == 1 process x 8 rows (two steps): the replicated step
     (all-reduce), the sharded step (reduce-scatter -> AdamW on 1/world -> all-gather of the operands; fp32 and bf16 compute)
     and the sharded step with the bf16 gradient payload.  Parameters, EMA and the next forward's output, on BOTH ranks."""
+    _ranks_equal_full_batch(tmp_path, mode, dtype, 2)
+
+
+def test_four_rank_sharded_step_equals_full_batch(tmp_path):
+    """The same with 4 ranks x 2 rows: the shard boundaries of every bucket fall inside other tensors than with 2 ranks
+    (a quarter of a layer's 12 d^2 weights = the fused q|k|v gradient exactly, then proj + half of mlp.0, ...)."""
+    _ranks_equal_full_batch(tmp_path, "sharded", "fp32", 4)
+
+
+def _ranks_equal_full_batch(tmp_path, mode, dtype, world):
     import socket
     import torch.multiprocessing as mp
     from gpt_amd.trainstep import TrainStep
@@ -345,11 +356,11 @@ def test_two_rank_step_equals_full_batch(tmp_path, mode, dtype):
         port = s.getsockname()[1]
     out_path = str(tmp_path / "rank")
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_ddp_rank, args=(r, 2, port, out_path, mode, dtype)) for r in range(2)]
+    procs = [ctx.Process(target=_ddp_rank, args=(r, world, port, out_path, mode, dtype)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(timeout=120)
+        p.join(timeout=150)
         if p.exitcode is None:
             p.kill()
         assert p.exitcode == 0
@@ -369,7 +380,7 @@ def test_two_rank_step_equals_full_batch(tmp_path, mode, dtype):
     # element whose gradient is below the bf16 noise floor gets a sign-like Adam update: single elements may differ by up to
     # 2 lr = 2e-3 after two steps, so the bar is on the maximum (< 2 lr) AND on the mean (< lr / 20)
     tol = 5e-5 if dtype == "fp32" else 2e-3
-    for rank in range(2):
+    for rank in range(world):
         got = torch.load(out_path + f".{rank}", weights_only=True)
         for name, ref_mod in (("params", m), ("ema", ts.ema)):
             for k, p in ref_mod.named_parameters():
