@@ -341,10 +341,12 @@ def test_two_rank_step_equals_full_batch(tmp_path, mode, dtype):
     _ranks_equal_full_batch(tmp_path, mode, dtype, 2)
 
 
-def test_four_rank_sharded_step_equals_full_batch(tmp_path):
-    """The same with 4 ranks x 2 rows: the shard boundaries of every bucket fall inside other tensors than with 2 ranks
-    (a quarter of a layer's 12 d^2 weights = the fused q|k|v gradient exactly, then proj + half of mlp.0, ...)."""
-    _ranks_equal_full_batch(tmp_path, "sharded", "fp32", 4)
+@pytest.mark.parametrize("world", [4, 8])
+def test_more_ranks_sharded_step_equals_full_batch(tmp_path, world):
+    """The same with 4 ranks x 2 rows and 8 ranks x 1 row (the driver's largest run): the shard boundaries of every bucket
+    fall inside other tensors than with 2 ranks (a quarter of a layer's 12 d^2 weights = the fused q|k|v gradient exactly,
+    then proj + half of mlp.0, ...)."""
+    _ranks_equal_full_batch(tmp_path, "sharded", "fp32", world)
 
 
 def _ranks_equal_full_batch(tmp_path, mode, dtype, world):
@@ -360,7 +362,7 @@ def _ranks_equal_full_batch(tmp_path, mode, dtype, world):
     for p in procs:
         p.start()
     for p in procs:
-        p.join(timeout=150)
+        p.join(timeout=240)
         if p.exitcode is None:
             p.kill()
         assert p.exitcode == 0
@@ -491,7 +493,7 @@ def test_ddp_static_graph_through_autograd_equals_full_batch(tmp_path):
     for p in procs:
         p.start()
     for p in procs:
-        p.join(timeout=150)
+        p.join(timeout=240)
         if p.exitcode is None:
             p.kill()
         assert p.exitcode == 0
