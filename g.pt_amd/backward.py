@@ -167,7 +167,7 @@ def can_overwrite_wgrads(eng, B):
     return _grouped_wgrads(eng, B) and os.environ.get("GPT_WGRAD_OVERWRITE", "1") != "0"
 
 
-def _descriptor(eng, buf, scratch, overwrite=False, defer=1):
+def _descriptor(eng, buf, scratch, overwrite=False, defer=1, sumsq=None):
     dec = eng.model.decoder
     ar = eng.arena
     base = buf.data_ptr()
@@ -190,6 +190,7 @@ def _descriptor(eng, buf, scratch, overwrite=False, defer=1):
         setattr(bw, k, L.ptr(t))
     bw.wgrad_overwrite = int(overwrite)
     bw.wgrad_defer = int(defer)
+    bw.wgrad_sumsq = L.ptr(sumsq) if sumsq is not None else None
     return bw, layers
 
 
@@ -207,7 +208,7 @@ def forward_keep(model, x, t, lt, lp, x_prev):
     return eng, ws, out
 
 
-def backward_into(eng, ws, x, x_prev, d_out, buf, schedule=None, overwrite=False):
+def backward_into(eng, ws, x, x_prev, d_out, buf, schedule=None, overwrite=False, sumsq=None):
     """Runs the backward of the last forward_keep on this engine, accumulating into the flat buffer `buf`.
 
     overwrite: the Blocks' weight gradients are stored, not accumulated (their part of `buf` need not be zero; only where
@@ -220,7 +221,8 @@ def backward_into(eng, ws, x, x_prev, d_out, buf, schedule=None, overwrite=False
     # Blocks are merged; with one, every stage range ends with its own launch (the C side merges inside one call only)
     defer = wgrad_defer_layers(eng, B) if not schedule else 1
     scratch = _scratch(eng, B, defer)
-    bw, keep = _descriptor(eng, buf, scratch, overwrite, defer)
+    # sumsq (a zeroed fp32 device scalar, store mode only): += the sum of squares of the Blocks' weight gradients
+    bw, keep = _descriptor(eng, buf, scratch, overwrite, defer, sumsq)
     n_stages = eng.model.decoder.n_layer + 2
     done = 0
     for stage_end, callback in list(schedule or []) + [(n_stages, None)]:

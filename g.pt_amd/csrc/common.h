@@ -76,3 +76,8 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
+
+// gpt_gemm_tn_grouped with one more (internal) argument: sumsq != NULL (store mode only) adds the sum of squares of every stored
+// tile to that device scalar (gpt_backward_t.wgrad_sumsq)
+int gpt_tn_grouped_sumsq(int n, const void* const* P, const int64_t* ldp, const void* const* Q, const int64_t* ldq, float* const* C,
+                         const int64_t* ldc, const int* I, const int* J, int R, int accumulate, float* sumsq, void* stream);

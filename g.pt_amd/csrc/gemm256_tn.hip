@@ -51,6 +51,7 @@ struct TnGroup {
   GemmArgs<bf16_t> g[TN_MAX_GROUP];
   int off[TN_MAX_GROUP + 1];
   int n, ksplit;
+  float* sumsq;   // store mode: += sum of squares of every stored tile (one float atomic per wave), or NULL
 };
 
 template <int EPI>
@@ -233,6 +234,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(TnGroup grp) {
         for (int e = 0; e < 4; ++e) c[(int64_t)e * g.ldc] = acc[i][j][e];
       }
     }
+  if constexpr (EPI == GPT_EPI_STORE_F32) {
+    if (grp.sumsq) {                                          // workgroup-uniform
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ss = fmaf(acc[i][j][e], acc[i][j][e], ss);
+      ss = wave_sum(ss);
+      if (lane == 0) unsafeAtomicAdd(grp.sumsq, ss);
+    }
+  }
 }
 
 // spans: estimated time (us) = rounds x (K-tiles per span x 1.5 + 10) + atomics at ~0.2 us per partial tile and CU round
@@ -307,10 +321,17 @@ extern "C" int gpt_gemm_tn(const void* P, int64_t ldp, const void* Q, int64_t ld
 extern "C" int gpt_gemm_tn_grouped(int n, const void* const* P, const int64_t* ldp, const void* const* Q, const int64_t* ldq,
                                    float* const* C, const int64_t* ldc, const int* I, const int* J, int R, int accumulate,
                                    void* stream) {
+  return gpt_tn_grouped_sumsq(n, P, ldp, Q, ldq, C, ldc, I, J, R, accumulate, nullptr, stream);
+}
+
+int gpt_tn_grouped_sumsq(int n, const void* const* P, const int64_t* ldp, const void* const* Q, const int64_t* ldq, float* const* C,
+                         const int64_t* ldc, const int* I, const int* J, int R, int accumulate, float* sumsq, void* stream) {
   using namespace gemmk;
+  GPT_REQUIRE(!sumsq || !accumulate, "gpt_gemm_tn_grouped: the sum of squares exists in store mode only");
   GPT_REQUIRE(n >= 1 && n <= TN_MAX_GROUP && P && ldp && Q && ldq && C && ldc && I && J, "gpt_gemm_tn_grouped: need 1..%d problems", TN_MAX_GROUP);
   TnGroup grp;
   grp.n = n;
+  grp.sumsq = sumsq;
   for (int p = 0; p < n; ++p) {
     const int rc = tn_check(P[p], ldp[p], Q[p], ldq[p], C[p], ldc[p], I[p], J[p], R);
     if (rc != 0) return rc;

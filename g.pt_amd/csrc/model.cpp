@@ -263,6 +263,7 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
               "gpt_denoiser_backward: wgrad_overwrite needs the grouped TN launch (bf16, B * T %% 64 == 0, n_embd %% 256 == 0)");
   // Deferred weight gradients (gpt_backward_t.wgrad_defer): Block l works in slot (L - 1 - l) % G of the dY buffers and its four
   // TN problems wait in `pend` until G Blocks are collected (or the call ends): one grid for all of them.
+  GPT_REQUIRE(!bw->wgrad_sumsq || bw->wgrad_overwrite, "gpt_denoiser_backward: wgrad_sumsq needs wgrad_overwrite");
   GPT_REQUIRE(bw->wgrad_defer >= 0 && bw->wgrad_defer <= 4, "gpt_denoiser_backward: wgrad_defer %d out of range (0..4)", bw->wgrad_defer);
   const int G = grouped && bw->wgrad_defer > 1 ? bw->wgrad_defer : 1;
   auto slot = [&](void* base, int sl, size_t width) { return (void*)((char*)base + (size_t)sl * M * width * es); };
@@ -275,8 +276,8 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
   } pend;
   auto flush = [&]() -> int {
     if (pend.n == 0) return 0;
-    const int rc = gpt_gemm_tn_grouped(pend.n, pend.P, pend.ldp, pend.Q, pend.ldq, pend.C, pend.ldc, pend.I, pend.J, M,
-                                       bw->wgrad_overwrite ? 0 : 1, stream);
+    const int rc = gpt_tn_grouped_sumsq(pend.n, pend.P, pend.ldp, pend.Q, pend.ldq, pend.C, pend.ldc, pend.I, pend.J, M,
+                                        bw->wgrad_overwrite ? 0 : 1, bw->wgrad_sumsq, stream);
     pend.n = 0;
     return rc;
   };

@@ -267,7 +267,13 @@ class TrainStep:
         # the Blocks' weight gradients (95 % of the arena) are STORED by the grouped weight-gradient launch where it applies:
         # no read-modify-write of the arena in its epilogue, and update() zeroes only what is still accumulated
         self._overwrote = self.fused and can_overwrite_wgrads(eng, B)
-        backward_into(eng, ws, x, xp, d_out, self.grads, schedule, overwrite=self._overwrote)
+        # one GPU, store-mode weight gradients: their share of |g|^2 comes out of the TN launch's accumulators (under data
+        # parallelism the norm is that of the SUMMED gradients, so it has to wait for the exchange)
+        self._tile_sumsq = None
+        if self._overwrote and schedule is None and self.grad_clip > 0 and os.environ.get("GPT_WGRAD_SUMSQ", "1") != "0":
+            self._tile_sumsq = self.norm_scratch[1028:1029]
+            self._tile_sumsq.zero_()
+        backward_into(eng, ws, x, xp, d_out, self.grads, schedule, overwrite=self._overwrote, sumsq=self._tile_sumsq)
         return mse
 
     @torch.no_grad()
@@ -311,7 +317,12 @@ class TrainStep:
                 self.eps, self.wd, self.iteration, self.ema_decay, zero_grad, st), "gpt_adamw_ema_step")
 
         if not self.shard:
-            if self.grad_clip > 0:
+            if self.grad_clip > 0 and getattr(self, "_tile_sumsq", None) is not None:
+                cut = self.arena.s_dec_start         # [0, cut): the Blocks' weights, summed by the TN launches already
+                part = self.norm_scratch[1026:1027]
+                L.check(lib.gpt_grad_sumsq(L.ptr(self.grads[cut:]), n - cut, L.ptr(self.norm_scratch), L.ptr(part), st), "gpt_grad_sumsq")
+                torch.add(part, self._tile_sumsq, out=self.grad_norm_sq)
+            elif self.grad_clip > 0:
                 L.check(lib.gpt_grad_sumsq(L.ptr(self.grads), n, L.ptr(self.norm_scratch), L.ptr(self.grad_norm_sq), st),
                         "gpt_grad_sumsq")
             if getattr(self, "_overwrote", False):

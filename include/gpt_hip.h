@@ -350,6 +350,10 @@ typedef struct {
    * four Blocks = 7 rounds instead of 8).  The operands of a deferred launch must survive the Blocks in between: gt, d_act and
    * d_qkv then hold G slots of [M, d], [M, 4d], [M, 3d] back to back (M = B * T of the call).  0 / 1: one launch per Block. */
   int wgrad_defer;
+  /* device fp32 scalar or NULL.  Non-NULL (needs wgrad_overwrite): every weight-gradient tile the grouped TN launch stores also
+   * adds the sum of its squares here (the caller zeroes it before the backward): the Blocks' share of the squared gradient norm
+   * that torch.nn.utils.clip_grad_norm_ (main.py:70) needs, taken from the accumulators instead of a second pass over 1.4 GB. */
+  float* wgrad_sumsq;
 } gpt_backward_t;
 
 /* Backward of gpt_denoiser_forward run on a layer_stride == 1 workspace: d_out[B, D] = dLoss/d(out).

@@ -1,5 +1,9 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 900 python -u -m pytest tests/test_hip_training.py -x -q -m gpu -k "more_ranks" --timeout 300 --timeout-method thread > gpurun_out/dp4.log 2>&1; rc=$?; tail -4 gpurun_out/dp4.log | cut -c1-300
-if grep -q "HSA_STATUS_ERROR\|Memory access fault" gpurun_out/dp4.log; then echo FAULT; exit 1; fi
-exit $rc
+timeout -k 10 900 python -u -m pytest tests/test_hip_training.py tests/test_hip_fullsize.py -x -q -m gpu --timeout 300 --timeout-method thread > gpurun_out/sumsq.log 2>&1; rc=$?; tail -3 gpurun_out/sumsq.log | cut -c1-200
+if grep -q "HSA_STATUS_ERROR\|Memory access fault" gpurun_out/sumsq.log; then echo FAULT; exit 1; fi
+[ $rc -eq 0 ] || exit $rc
+for v in 0 1 0 1; do
+echo "== GPT_WGRAD_SUMSQ=$v"
+GPT_WGRAD_SUMSQ=$v timeout -k 10 300 python bench.py --mode train --batch 128 --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('final_loss'))" || exit 1
+done
