@@ -243,3 +243,33 @@ def test_second_training_forward_before_backward_is_an_error():
     out3.sum().backward()
     # (LayerNorm's dgamma / dbeta are accumulated with float atomics: equal up to the order of the additions)
     assert torch.allclose(m.decoder.ln_f.weight.grad, g2, rtol=1e-4, atol=1e-5)
+
+
+def test_deferred_weight_gradient_launches_and_tile_sumsq(monkeypatch):
+    """gpt_backward_t.wgrad_defer / wgrad_sumsq at the real width (12 layers, d = 1536, bf16, store mode): merging the grouped
+    weight-gradient launches of four Blocks changes WHEN a tile is computed, not how - the gradient arena is bit-identical to
+    the one-launch-per-Block backward; and the sum of squares the TN launches add up equals that of the stored gradients."""
+    from gpt_amd.backward import backward_into, forward_keep, can_overwrite_wgrads
+    m, plan, sd = build("mnist", "bf16", seed=41)
+    m.train()
+    x, t, lt, lp, xp = (v.to(DEV) for v in make_inputs("mnist", B=32, seed=77))
+    xx, tt, l1, l2, xpp = m._prepare(x, t, lt, lp, xp)
+    d_out = torch.randn(x.shape, generator=torch.Generator().manual_seed(5)).to(DEV) * 1e-2
+    bufs, sums = {}, {}
+    for defer in ("1", "4"):
+        monkeypatch.setenv("GPT_WGRAD_DEFER", defer)
+        eng, ws, out = forward_keep(m, xx, tt, l1, l2, xpp)
+        assert can_overwrite_wgrads(eng, 32)
+        buf = torch.full((eng.arena.numel,), float("nan"), device=DEV)       # store mode must not read the Blocks' weights
+        buf[eng.arena.s_dec_start:] = 0.0
+        ss = torch.zeros(1, device=DEV)
+        backward_into(eng, ws, xx, xpp, d_out, buf, overwrite=True, sumsq=ss)
+        torch.cuda.synchronize()
+        bufs[defer], sums[defer] = buf.cpu(), float(ss)
+    assert bool(torch.isfinite(bufs["1"]).all())
+    cut = eng.arena.s_dec_start
+    assert torch.equal(bufs["1"][:cut], bufs["4"][:cut])                      # the Blocks' weights: the same tiles, bit for bit
+    # biases, LayerNorm parameters, ...: summed with float atomics, equal to rounding only
+    assert torch.allclose(bufs["1"][cut:], bufs["4"][cut:], rtol=1e-3, atol=1e-6)
+    want = float((bufs["4"][:cut].double() ** 2).sum())
+    assert want > 0 and abs(sums["4"] - want) < 1e-4 * want and abs(sums["1"] - want) < 1e-4 * want
