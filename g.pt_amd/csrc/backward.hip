@@ -184,38 +184,212 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, in
 // C[m, n] (+)= sum_k A(m, k) * B(k, n), exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), arbitrary element strides: the
 // ragged encoder / decoder gradients (0.4 % of the FLOPs; K = batch or a token width).  64 x 64 tile per workgroup
 // (one 32 x 32 accumulator per wave), 32-deep chunks staged through LDS so either operand may be K- or M/N-major.
-// One operand's [KC x 64] chunk into LDS when its M / N index is the contiguous one (the gradients whose contraction runs over
-// the batch): 16-byte loads along the row instead of one element per lane and iteration - the element-wise staging, not the
-// MFMAs, was what these launches spent their time on.  vec_ok: base and row stride are 16-byte aligned (else per element).
+// An operand's [KC x 64] chunk is 8 elements per thread.  VEC: its M / N index is the contiguous one, base and row stride are
+// 16-byte aligned and the extent is a multiple of the vector width (the products that contract over the batch, big tokens):
+// 16-byte loads along the row.  Otherwise one element per load, laid out along whichever index is contiguous.
+// r02: the staging is a two-stage register pipeline (the loads of chunk c + 2 are issued before the MFMAs of chunk c; r01 loaded,
+// stored and multiplied one chunk at a time: one exposed memory latency per 32 of K) written so that hipcc's wait insertion can
+// count (see tokens.hip): no branch around a load (clamped addresses), zeroing and widening at the LDS store, pairs of chunks.
 constexpr int SG_KC = 32, SG_PITCH = 68;   // 68 floats: 16-byte aligned rows, conflict-free 32-lane reads
-template <typename T>
-__device__ __forceinline__ void sg_stage_contig(float (*S)[SG_PITCH], const T* __restrict__ base, int64_t sk, int i0, int I, int k0,
-                                                int K, bool vec_ok) {
-  constexpr int VE = 16 / sizeof(T), VPR = 64 / VE;     // elements per 16 bytes, vectors per 64-wide row
-  for (int i = threadIdx.x; i < SG_KC * VPR; i += 256) {
-    const int kk = i / VPR, iv = (i % VPR) * VE;
-    const int k = k0 + kk, idx = i0 + iv;
-    float vals[VE];
-    const T* p = base + (int64_t)k * sk + idx;
-    if (k < K && idx + VE <= I && vec_ok) {
-      const u32x4 raw = *reinterpret_cast<const u32x4*>(p);
-      if constexpr (sizeof(T) == 4) {
+
+template <typename T, bool VEC>
+struct SgStage {
+  uint32_t r[8];
+  int k0;
+  // element e of this thread in scalar mode: flat index i = tid + 256 e of the chunk, along k if the operand is K-major
+  __device__ __forceinline__ static void pos(int i, bool kmajor, int& kk, int& ii) {
+    kk = kmajor ? (i & (SG_KC - 1)) : (i >> 6);
+    ii = kmajor ? (i >> 5) : (i & 63);
+  }
+  __device__ __forceinline__ void load(const T* __restrict__ base, int64_t s_i, int64_t s_k, int i0, int I, int k0_, int K) {
+    k0 = k0_;
+    if constexpr (VEC) {
+      constexpr int VE = 16 / sizeof(T), VPR = 64 / VE, NVEC = SG_KC * VPR / 256;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) vals[e] = __uint_as_float(raw[e]);
-      } else {
+      for (int j = 0; j < NVEC; ++j) {
+        const int i = threadIdx.x + 256 * j, kk = i / VPR, iv = (i % VPR) * VE;
+        const int k = min(k0 + kk, K - 1), idx = i0 + iv < I ? i0 + iv : 0;
+        const u32x4 raw = *reinterpret_cast<const u32x4*>(base + (int64_t)k * s_k + idx);
+        r[4 * j] = raw.x; r[4 * j + 1] = raw.y; r[4 * j + 2] = raw.z; r[4 * j + 3] = raw.w;
+      }
+    } else {
+      const bool kmajor = s_k == 1;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          vals[2 * e] = __uint_as_float(raw[e] << 16);
-          vals[2 * e + 1] = __uint_as_float(raw[e] & 0xffff0000u);
+      for (int e = 0; e < 8; ++e) {
+        int kk, ii;
+        pos(threadIdx.x + 256 * e, kmajor, kk, ii);
+        const T* p = base + (int64_t)min(i0 + ii, I - 1) * s_i + (int64_t)min(k0 + kk, K - 1) * s_k;
+        if constexpr (sizeof(T) == 4) r[e] = __float_as_uint(*p);
+        else r[e] = (uint32_t)*p;                               // widened at the store: nothing here may consume the load
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float (*S)[SG_PITCH], int64_t s_k, int i0, int I, int K) const {
+    __builtin_amdgcn_sched_barrier(0);   // what follows consumes the loads: it must not be scheduled into the chunk before
+    if constexpr (VEC) {
+      constexpr int VE = 16 / sizeof(T), VPR = 64 / VE, NVEC = SG_KC * VPR / 256;
+#pragma unroll
+      for (int j = 0; j < NVEC; ++j) {
+        const int i = threadIdx.x + 256 * j, kk = i / VPR, iv = (i % VPR) * VE;
+        const bool ok = k0 + kk < K && i0 + iv < I;                 // I % VE == 0: a vector is all inside or all outside
+        if constexpr (sizeof(T) == 4) {
+          *reinterpret_cast<f32x4*>(&S[kk][iv]) = f32x4{ok ? __uint_as_float(r[4 * j]) : 0.f, ok ? __uint_as_float(r[4 * j + 1]) : 0.f,
+                                                        ok ? __uint_as_float(r[4 * j + 2]) : 0.f, ok ? __uint_as_float(r[4 * j + 3]) : 0.f};
+        } else {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[2 * e] = ok ? __uint_as_float(r[4 * j + e] << 16) : 0.f;
+            v[2 * e + 1] = ok ? __uint_as_float(r[4 * j + e] & 0xffff0000u) : 0.f;
+          }
+          *reinterpret_cast<f32x4*>(&S[kk][iv]) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(&S[kk][iv + 4]) = f32x4{v[4], v[5], v[6], v[7]};
         }
       }
     } else {
+      const bool kmajor = s_k == 1;
 #pragma unroll
-      for (int e = 0; e < VE; ++e) vals[e] = (k < K && idx + e < I) ? elem<T>::load(p + e) : 0.f;
+      for (int e = 0; e < 8; ++e) {
+        int kk, ii;
+        pos(threadIdx.x + 256 * e, kmajor, kk, ii);
+        S[kk][ii] = (k0 + kk < K && i0 + ii < I) ? __uint_as_float(sizeof(T) == 4 ? r[e] : r[e] << 16) : 0.f;
+      }
     }
-#pragma unroll
-    for (int e = 0; e < VE; e += 4) *reinterpret_cast<f32x4*>(&S[kk][iv + e]) = f32x4{vals[e], vals[e + 1], vals[e + 2], vals[e + 3]};
   }
+};
+
+// bf16 compute mode: the same chunk as bf16 in LDS, [KC][SG_P16] (k-major rows of 64 + 8 columns), for the bf16 matrix pipe
+constexpr int SG_P16 = 72;
+template <typename T, bool VEC>
+__device__ __forceinline__ void sg_store_bf16(const SgStage<T, VEC>& st, unsigned short (*S)[SG_P16], int64_t s_k, int i0, int I, int K) {
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (VEC) {
+    constexpr int VE = 16 / sizeof(T), VPR = 64 / VE, NVEC = SG_KC * VPR / 256;
+#pragma unroll
+    for (int j = 0; j < NVEC; ++j) {
+      const int i = threadIdx.x + 256 * j, kk = i / VPR, iv = (i % VPR) * VE;
+      const bool ok = st.k0 + kk < K && i0 + iv < I;
+      if constexpr (sizeof(T) == 4) {
+        uint2 o;
+        o.x = ok ? pack_bf16x2(__uint_as_float(st.r[4 * j]), __uint_as_float(st.r[4 * j + 1])) : 0u;
+        o.y = ok ? pack_bf16x2(__uint_as_float(st.r[4 * j + 2]), __uint_as_float(st.r[4 * j + 3])) : 0u;
+        *reinterpret_cast<uint2*>(&S[kk][iv]) = o;
+      } else {
+        *reinterpret_cast<u32x4*>(&S[kk][iv]) = u32x4{ok ? st.r[4 * j] : 0u, ok ? st.r[4 * j + 1] : 0u, ok ? st.r[4 * j + 2] : 0u, ok ? st.r[4 * j + 3] : 0u};
+      }
+    }
+  } else {
+    const bool kmajor = s_k == 1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int kk, ii;
+      SgStage<T, VEC>::pos(threadIdx.x + 256 * e, kmajor, kk, ii);
+      const bool ok = st.k0 + kk < K && i0 + ii < I;
+      unsigned short v;
+      if constexpr (sizeof(T) == 4) v = (unsigned short)(pack_bf16x2(__uint_as_float(st.r[e]), 0.f) & 0xffffu);
+      else v = (unsigned short)st.r[e];
+      S[kk][ii] = ok ? v : (unsigned short)0;
+    }
+  }
+}
+
+typedef short sg_v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) sg_v4s* sg_lds_v4s_ptr;
+
+// The same tile on the bf16 matrix pipe (bf16 compute mode): operands rounded to bf16 on their way into LDS (as every other weight
+// / input gradient of that mode sees them), v_mfma_f32_16x16x32_bf16 with fragments gathered by ds_read_b64_tr_b16 from the k-major
+// chunk, fp32 accumulation.  The exact-fp32 pipe (256 FLOP per clock and CU) bounded the fp32 tile at the large batches: the encoder
+// weight gradients are 53 GFLOP at B = 1024 = 340 us at its peak, 483 us measured.
+template <typename TA, typename TB>
+__device__ __forceinline__ void small_gemm_tile_bf16(const TA* __restrict__ A, int64_t a_sm, int64_t a_sk,
+                                                     const TB* __restrict__ B, int64_t b_sk, int64_t b_sn,
+                                                     float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                     int accumulate) {
+  constexpr int KC = SG_KC;
+  __shared__ __attribute__((aligned(16))) unsigned short As[KC][SG_P16], Bs[KC][SG_P16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  constexpr int VA = 16 / sizeof(TA), VB = 16 / sizeof(TB);
+  const bool a_vec = a_sm == 1 && ((uintptr_t)A % 16) == 0 && (a_sk * (int64_t)sizeof(TA)) % 16 == 0 && M % VA == 0;
+  const bool b_vec = b_sn == 1 && ((uintptr_t)B % 16) == 0 && (b_sk * (int64_t)sizeof(TB)) % 16 == 0 && N % VB == 0;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // transposing read: the 16-lane group gq reads rows (k) 8 gq + tq (then + 4), columns c0 + 4 tp .. + 3; lane i of the group
+  // receives column c0 + i of the four rows: its 8 consecutive k of one m / n (the 16x16x32 operand)
+  const int gq = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  auto frag = [&](const unsigned short (*S)[SG_P16], int c0) {
+    const char* base = reinterpret_cast<const char*>(&S[8 * gq + tq][c0 + 4 * tp]);
+    const sg_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sg_lds_v4s_ptr)base);
+    const sg_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sg_lds_v4s_ptr)(base + 4 * SG_P16 * 2));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto mma = [&]() {
+    bf16x8 a[2], b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = frag(As, wm + 16 * i);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[j] = frag(Bs, wn + 16 * j);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+  };
+  const int nchunk = (K + KC - 1) / KC, last = nchunk - 1;
+  auto run = [&](auto av, auto bv) {
+    SgStage<TA, decltype(av)::value> a0, a1;
+    SgStage<TB, decltype(bv)::value> b0, b1;
+    a0.load(A, a_sm, a_sk, m0, M, 0, K);
+    b0.load(B, b_sn, b_sk, n0, N, 0, K);
+    a1.load(A, a_sm, a_sk, m0, M, min(1, last) * KC, K);
+    b1.load(B, b_sn, b_sk, n0, N, min(1, last) * KC, K);
+    for (int c = 0; c + 1 < nchunk; c += 2) {
+      sg_store_bf16(a0, As, a_sk, m0, M, K);
+      sg_store_bf16(b0, Bs, b_sk, n0, N, K);
+      __syncthreads();
+      a0.load(A, a_sm, a_sk, m0, M, min(c + 2, last) * KC, K);
+      b0.load(B, b_sn, b_sk, n0, N, min(c + 2, last) * KC, K);
+      mma();
+      __syncthreads();
+      sg_store_bf16(a1, As, a_sk, m0, M, K);
+      sg_store_bf16(b1, Bs, b_sk, n0, N, K);
+      __syncthreads();
+      a1.load(A, a_sm, a_sk, m0, M, min(c + 3, last) * KC, K);
+      b1.load(B, b_sn, b_sk, n0, N, min(c + 3, last) * KC, K);
+      mma();
+      __syncthreads();
+    }
+    if (nchunk & 1) {
+      sg_store_bf16(a0, As, a_sk, m0, M, K);
+      sg_store_bf16(b0, Bs, b_sk, n0, N, K);
+      __syncthreads();
+      mma();
+    }
+  };
+  using Yes = std::integral_constant<bool, true>;
+  using No = std::integral_constant<bool, false>;
+  if (a_vec && b_vec) run(Yes{}, Yes{});
+  else if (a_vec) run(Yes{}, No{});
+  else if (b_vec) run(No{}, Yes{});
+  else run(No{}, No{});
+  // C/D map of the 16x16 MFMA: col (n) = lane & 15, row (m) = 4 * (lane >> 4) + reg
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn + 16 * j + (lane & 15);
+      if (n >= N) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + wm + 16 * i + 4 * (lane >> 4) + e;
+        if (m >= M) continue;
+        float* c = C + (int64_t)m * ldc + n;
+        *c = accumulate ? *c + acc[i][j][e] : acc[i][j][e];
+      }
+    }
 }
 
 template <typename TA, typename TB>
@@ -228,42 +402,58 @@ __device__ __forceinline__ void small_gemm_tile(const TA* __restrict__ A, int64_
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  const bool a_vec = a_sm == 1 && ((uintptr_t)A % 16) == 0 && (a_sk * (int64_t)sizeof(TA)) % 16 == 0;
-  const bool b_vec = b_sn == 1 && ((uintptr_t)B % 16) == 0 && (b_sk * (int64_t)sizeof(TB)) % 16 == 0;
+  constexpr int VA = 16 / sizeof(TA), VB = 16 / sizeof(TB);
+  const bool a_vec = a_sm == 1 && ((uintptr_t)A % 16) == 0 && (a_sk * (int64_t)sizeof(TA)) % 16 == 0 && M % VA == 0;
+  const bool b_vec = b_sn == 1 && ((uintptr_t)B % 16) == 0 && (b_sk * (int64_t)sizeof(TB)) % 16 == 0 && N % VB == 0;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int k0 = 0; k0 < K; k0 += KC) {
-    if (a_sm == 1) {
-      sg_stage_contig<TA>(As, A, a_sk, m0, M, k0, K, a_vec);
-    } else {
-      for (int i = threadIdx.x; i < KC * 64; i += 256) {
-        // lay the loads out along whichever index is contiguous in memory
-        int kk, mm;
-        if (a_sk == 1) { kk = i & (KC - 1); mm = i / KC; } else { mm = i & 63; kk = i >> 6; }
-        const int m = m0 + mm, k = k0 + kk;
-        As[kk][mm] = (m < M && k < K) ? elem<TA>::load(A + m * a_sm + k * a_sk) : 0.f;
-      }
-    }
-    if (b_sn == 1) {
-      sg_stage_contig<TB>(Bs, B, b_sk, n0, N, k0, K, b_vec);
-    } else {
-      for (int i = threadIdx.x; i < KC * 64; i += 256) {
-        int kb, nn;
-        if (b_sk == 1) { kb = i & (KC - 1); nn = i / KC; } else { nn = i & 63; kb = i >> 6; }
-        const int n = n0 + nn, k2 = k0 + kb;
-        Bs[kb][nn] = (n < N && k2 < K) ? elem<TB>::load(B + k2 * b_sk + n * b_sn) : 0.f;
-      }
-    }
-    __syncthreads();
+  auto mma = [&]() {
 #pragma unroll
     for (int kk = 0; kk < KC; kk += 2) {
       const float a = As[kk + (lane >> 5)][wm + (lane & 31)];
       const float b = Bs[kk + (lane >> 5)][wn + (lane & 31)];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
-    __syncthreads();
-  }
+  };
+  const int nchunk = (K + KC - 1) / KC, last = nchunk - 1;
+  // the whole K loop once per pair of staging modes (workgroup-uniform): no branch on them inside it
+  auto run = [&](auto av, auto bv) {
+    SgStage<TA, decltype(av)::value> a0, a1;
+    SgStage<TB, decltype(bv)::value> b0, b1;
+    a0.load(A, a_sm, a_sk, m0, M, 0, K);
+    b0.load(B, b_sn, b_sk, n0, N, 0, K);
+    a1.load(A, a_sm, a_sk, m0, M, min(1, last) * KC, K);       // past the last chunk the last one is loaded again: no branch
+    b1.load(B, b_sn, b_sk, n0, N, min(1, last) * KC, K);
+    for (int c = 0; c + 1 < nchunk; c += 2) {
+      a0.store(As, a_sk, m0, M, K);
+      b0.store(Bs, b_sk, n0, N, K);
+      __syncthreads();
+      a0.load(A, a_sm, a_sk, m0, M, min(c + 2, last) * KC, K);
+      b0.load(B, b_sn, b_sk, n0, N, min(c + 2, last) * KC, K);
+      mma();
+      __syncthreads();
+      a1.store(As, a_sk, m0, M, K);
+      b1.store(Bs, b_sk, n0, N, K);
+      __syncthreads();
+      a1.load(A, a_sm, a_sk, m0, M, min(c + 3, last) * KC, K);
+      b1.load(B, b_sn, b_sk, n0, N, min(c + 3, last) * KC, K);
+      mma();
+      __syncthreads();
+    }
+    if (nchunk & 1) {                                           // stage 0 holds the last chunk
+      a0.store(As, a_sk, m0, M, K);
+      b0.store(Bs, b_sk, n0, N, K);
+      __syncthreads();
+      mma();
+    }
+  };
+  using Yes = std::integral_constant<bool, true>;
+  using No = std::integral_constant<bool, false>;
+  if (a_vec && b_vec) run(Yes{}, Yes{});
+  else if (a_vec) run(Yes{}, No{});
+  else if (b_vec) run(No{}, Yes{});
+  else run(No{}, No{});
   const int n = n0 + wn + (lane & 31);
   if (n < N) {
 #pragma unroll
@@ -296,13 +486,17 @@ struct SmallGemmBatch {
   int accumulate;
 };
 
-template <typename TA, typename TB>
+template <typename TA, typename TB, bool BF16_MMA>
 __global__ __launch_bounds__(256) void small_gemm_batched_kernel(SmallGemmBatch g) {
   const int z = blockIdx.z;
   const int M = g.M[z], N = g.N[z];
   if ((int)blockIdx.y * 64 >= M || (int)blockIdx.x * 64 >= N) return;      // uniform per workgroup
-  small_gemm_tile<TA, TB>((const TA*)g.A[z], g.a_sm, g.a_sk, (const TB*)g.B[z], g.b_sk, g.b_sn, g.C[z], g.ldc[z], M, N, g.K[z],
-                          g.accumulate);
+  if constexpr (BF16_MMA)
+    small_gemm_tile_bf16<TA, TB>((const TA*)g.A[z], g.a_sm, g.a_sk, (const TB*)g.B[z], g.b_sk, g.b_sn, g.C[z], g.ldc[z], M, N, g.K[z],
+                                 g.accumulate);
+  else
+    small_gemm_tile<TA, TB>((const TA*)g.A[z], g.a_sm, g.a_sk, (const TB*)g.B[z], g.b_sk, g.b_sn, g.C[z], g.ldc[z], M, N, g.K[z],
+                            g.accumulate);
 }
 
 // ------------------------------------------------------------------------------------------ attention backward
@@ -690,6 +884,14 @@ extern "C" int gpt_small_gemm_batched(int n_problems, int a_dtype, const void* c
                                       int b_dtype, const void* const* host_B, int64_t b_sk, int64_t b_sn, float* const* host_C,
                                       const int* host_ldc, const int* host_M, const int* host_N, const int* host_K,
                                       int accumulate, void* stream) {
+  return gpt_small_gemm_batched_mode(n_problems, a_dtype, host_A, a_sm, a_sk, b_dtype, host_B, b_sk, b_sn, host_C, host_ldc, host_M,
+                                     host_N, host_K, accumulate, 0, stream);
+}
+
+int gpt_small_gemm_batched_mode(int n_problems, int a_dtype, const void* const* host_A, int64_t a_sm, int64_t a_sk, int b_dtype,
+                                const void* const* host_B, int64_t b_sk, int64_t b_sn, float* const* host_C, const int* host_ldc,
+                                const int* host_M, const int* host_N, const int* host_K, int accumulate, int bf16_mma,
+                                void* stream) {
   GPT_REQUIRE(n_problems > 0 && n_problems <= SG_MAX_PROBLEMS, "gpt_small_gemm_batched: 1..%d problems", SG_MAX_PROBLEMS);
   GPT_REQUIRE(host_A && host_B && host_C && host_ldc && host_M && host_N && host_K, "gpt_small_gemm_batched: null array");
   SmallGemmBatch g;
@@ -705,7 +907,12 @@ extern "C" int gpt_small_gemm_batched(int n_problems, int a_dtype, const void* c
   g.a_sm = a_sm; g.a_sk = a_sk; g.b_sk = b_sk; g.b_sn = b_sn; g.accumulate = accumulate;
   const dim3 grid((max_n + 63) / 64, (max_m + 63) / 64, n_problems), block(256);
   hipStream_t s = (hipStream_t)stream;
-#define SGB(TA, TB) hipLaunchKernelGGL((small_gemm_batched_kernel<TA, TB>), grid, block, 0, s, g)
+  static const bool allow16 = [] { const char* e = getenv("GPT_SMALL_GEMM_BF16"); return !e || atoi(e) != 0; }();   // 0: always the exact pipe (A/B)
+#define SGB(TA, TB)                                                                                        \
+  do {                                                                                                     \
+    if (bf16_mma && allow16) hipLaunchKernelGGL((small_gemm_batched_kernel<TA, TB, true>), grid, block, 0, s, g); \
+    else hipLaunchKernelGGL((small_gemm_batched_kernel<TA, TB, false>), grid, block, 0, s, g);            \
+  } while (0)
   const bool ab = a_dtype == GPT_BF16, bb = b_dtype == GPT_BF16;
   if (ab && bb) SGB(bf16_t, bf16_t);
   else if (ab) SGB(bf16_t, float);

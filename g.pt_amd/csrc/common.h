@@ -81,3 +81,10 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 // tile to that device scalar (gpt_backward_t.wgrad_sumsq)
 int gpt_tn_grouped_sumsq(int n, const void* const* P, const int64_t* ldp, const void* const* Q, const int64_t* ldq, float* const* C,
                          const int64_t* ldc, const int* I, const int* J, int R, int accumulate, float* sumsq, void* stream);
+
+// gpt_small_gemm_batched with one more (internal) argument: bf16_mma != 0 rounds both operands to bf16 and multiplies them on the
+// bf16 matrix pipe (the denoiser backward in bf16 compute mode); 0 = the exact-fp32 pipe
+int gpt_small_gemm_batched_mode(int n_problems, int a_dtype, const void* const* host_A, int64_t a_sm, int64_t a_sk, int b_dtype,
+                                const void* const* host_B, int64_t b_sk, int64_t b_sn, float* const* host_C, const int* host_ldc,
+                                const int* host_M, const int* host_N, const int* host_K, int accumulate, int bf16_mma,
+                                void* stream);

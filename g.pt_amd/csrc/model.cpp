@@ -205,6 +205,7 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
   const int64_t Mp = ((int64_t)M + 63) / 64 * 64;
   const int W = 2 * m->nfreq + 1;
   hipStream_t hs = (hipStream_t)stream;
+  const int mma16 = dt == GPT_BF16;   // the ragged encoder / decoder gradients on the bf16 matrix pipe in bf16 compute mode
   auto xbuf = [&](int idx) { return ws->x + (size_t)idx * Mmax * d; };
   auto lay = [&](void* base, int l, size_t width) { return (void*)((char*)base + (size_t)l * Mmax * width * es); };
   auto stat = [&](int idx, int which) { return ws->stats + ((size_t)idx * 2 + which) * Mmax; };
@@ -242,9 +243,9 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
       vB[j] = B; vd[j] = d; vn[j] = m->dec_n[j]; vTd[j] = T * d;
     }
     // d_tok[b, j, :] = d_out[b, off_j ..] . W_j            (M = B, N = d, K = n_j)
-    CHECK(gpt_small_gemm_batched(m->n_out_tok, GPT_F32, pa, m->D, 1, dt, pw, d, 1, pt, vTd, vB, vd, vn, 0, stream));
+    CHECK(gpt_small_gemm_batched_mode(m->n_out_tok, GPT_F32, pa, m->D, 1, dt, pw, d, 1, pt, vTd, vB, vd, vn, 0, mma16, stream));
     // dW_j[n, :] += sum_b d_out[b, off_j + n] hf[b, j, :]   (M = n_j, N = d, K = B)
-    CHECK(gpt_small_gemm_batched(m->n_out_tok, GPT_F32, pa, 1, m->D, dt, ph, (int64_t)T * d, 1, pg, vd, vn, vd, vB, 1, stream));
+    CHECK(gpt_small_gemm_batched_mode(m->n_out_tok, GPT_F32, pa, 1, m->D, dt, ph, (int64_t)T * d, 1, pg, vd, vn, vd, vB, 1, mma16, stream));
   }
   // bw->g / bw->gt = gradient of the residual stream behind the last Block = dY of its mlp.2: the bias gradient g_b2 is its column sum,
   // taken by the LayerNorm backward that produces it (and so for every Block below: ln1's backward of Block l + 1 feeds Block l's mlp.2,
@@ -356,8 +357,8 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
         vM[n] = d; vN[n] = m->enc_k[i]; vK[n] = B; vld[n] = m->enc_k[i];
         ++n;
       }
-      if (n) CHECK(gpt_small_gemm_batched(n, GPT_F32, pa, 1, (int64_t)T * d, GPT_F32, pb, pass ? ld_scal : (int64_t)m->D, 1, pc, vld,
-                                          vM, vN, vK, 1, stream));
+      if (n) CHECK(gpt_small_gemm_batched_mode(n, GPT_F32, pa, 1, (int64_t)T * d, GPT_F32, pb, pass ? ld_scal : (int64_t)m->D, 1, pc, vld,
+                                               vM, vN, vK, 1, mma16, stream));
     }
   }
   return 0;

@@ -237,8 +237,12 @@ def test_fused_step_matches_torch_optimizer_over_steps():
         for k in a:
             if k.endswith("attn.key.bias"):
                 continue      # its true gradient is zero (softmax is shift invariant): Adam normalises pure rounding noise
-            # bf16 operand rounding can flip a few low bits of the gradients between the two runs' packed weights
-            assert float((a[k] - b[k]).abs().max()) < 2e-4 * max(1.0, float(b[k].abs().max())), k
+            # the atomically summed gradients differ in their last bits between any two runs, a weight on a bf16 rounding boundary
+            # then packs differently, and Adam's first steps are sign-like: single elements may move by a good part of lr = 1e-3
+            # over five steps - a bar on the maximum (< lr / 2) and a much tighter one on the mean
+            dk = (a[k] - b[k]).abs()
+            assert float(dk.max()) < 5e-4 * max(1.0, float(b[k].abs().max())), k
+            assert float(dk.mean()) < 1e-5, k
 
 
 def test_store_mode_weight_gradients_equal_accumulation(monkeypatch):
@@ -269,7 +273,12 @@ def test_store_mode_weight_gradients_equal_accumulation(monkeypatch):
     for k in runs[0]:
         if k.endswith("attn.key.bias"):
             continue
-        assert float((runs[0][k] - runs[1][k]).abs().max()) < 2e-4 * max(1.0, float(runs[1][k].abs().max())), k
+        # the atomically summed gradients (and, in store mode, the norm taken from the tiles) differ in their last bits between
+        # any two runs; Adam's first steps are sign-like, so a single element with a near-zero gradient may move by a good part
+        # of lr = 1e-3: a bar on the maximum (< lr / 2) and a much tighter one on the mean
+        dk = (runs[0][k] - runs[1][k]).abs()
+        assert float(dk.max()) < 5e-4 * max(1.0, float(runs[1][k].abs().max())), k
+        assert float(dk.mean()) < 1e-5, k
     # a batch the grouped launch does not take (B * T % 64 != 0): the flag must stay off and the step must work
     m, plan, sd = build("cifar_small", "bf16", seed=4)
     m.train()
