@@ -328,8 +328,11 @@ class _Engine:
             import numpy as np
             table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dev)
             self.items = (table, len(items), first4)
+        ready = getattr(self, "_ready", None)
         self.keep, self.cmodel, self.clayers = keep, cm, layers
         self._ready = None
+        if ready is not None:                   # a rebuild of the pointer tables must not drop waits that are still owed
+            self.set_ready(*ready)
 
     def set_ready(self, layer_events, dec_event):
         """Operands delivered asynchronously (TrainStep's all-gather of the other ranks' shards): the forward waits for
