@@ -357,6 +357,8 @@ typedef struct {
 } gpt_backward_t;
 
 /* Backward of gpt_denoiser_forward run on a layer_stride == 1 workspace: d_out[B, D] = dLoss/d(out).
+ * In GPT_BF16 mode every product of the backward, the ragged encoder / decoder gradients included, multiplies bf16-rounded
+ * operands with fp32 accumulation (GPT_F32: exact fp32 throughout).
  * x / x_prev / t inputs are not differentiated (training_losses needs parameter gradients only). */
 int gpt_denoiser_backward(const gpt_model_t* m, const gpt_workspace_t* ws, const gpt_backward_t* bw, const float* x,
                           const float* x_prev, const float* d_out, int B, void* stream);
