@@ -638,6 +638,17 @@ static int pick_spans_ln(int M, int N, int K, int* rt) {
   // K-tiles): half-height tiles while they leave room for two spans, spans of >= 8 K-tiles.
   int sp = n_cus() / tiles256;
   if (sp > nk / 16) sp = nk / 16;
+  // long K, many spans: half-height tiles need half the spans to fill the chip (fc2 at M = 1664: 78 tiles x 3 spans instead of
+  // 42 x 6), i.e. half the fp32 partial tiles for pass 2 to read: B = 64 sampling 1.958 -> 1.892 ms/step
+  static const bool prefer128 = [] { const char* e = getenv("GPT_LN_PREFER128"); return !e || atoi(e) != 0; }();   // 0: A/B
+  if (prefer128 && sp >= 4 && tiles128 * 2 <= n_cus()) {
+    int sp128 = n_cus() / tiles128;
+    if (sp128 > nk / 16) sp128 = nk / 16;
+    if (sp128 >= 2 && sp128 * 2 <= sp) {
+      *rt = 4;
+      sp = sp128;
+    }
+  }
   if (sp < 2) {
     const int tiles = tiles128 * 2 <= n_cus() ? tiles128 : tiles256;
     *rt = tiles == tiles128 ? 4 : 8;
