@@ -111,7 +111,9 @@ class TrainStep:
         out = [(ar.s_dec_start, ar.s_end, 1, "S")]
         hi = Lr
         while hi > 0:
-            lo = max(0, hi - bucket_layers)
+            # the blocks the backward reaches last go out one by one: what is still on the wire when the backward ends is
+            # the exposed tail of the exchange (113 MB instead of 226 MB at the mnist shapes)
+            lo = max(0, hi - (bucket_layers if hi > bucket_layers + 1 else 1))
             out.append((starts[lo], starts[hi], Lr - lo + 1, "S"))
             hi = lo
         out.append((ar.r_start, ar.numel, Lr + 2, "R"))
