@@ -88,3 +88,8 @@ int gpt_small_gemm_batched_mode(int n_problems, int a_dtype, const void* const* 
                                 const void* const* host_B, int64_t b_sk, int64_t b_sn, float* const* host_C, const int* host_ldc,
                                 const int* host_M, const int* host_N, const int* host_K, int accumulate, int bf16_mma,
                                 void* stream);
+
+// gpt_gemm_nt with one more (internal) argument: colsum != NULL (GPT_EPI_DGELU only) += the column sums of the output, i.e. the
+// bias gradient of the Linear whose output gradient the call produces, from the epilogue instead of a second pass (fp32 atomics)
+int gpt_gemm_nt_colsum(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc,
+                       void* aux, int64_t ldaux, int M, int N, int K, int epilogue, float* colsum, void* stream);

@@ -543,7 +543,8 @@ template <typename T>
 int dispatch(const GemmArgs<T>& g, int epi, hipStream_t s) {
   const int tiles256 = ((g.M + 255) / 256) * ((g.N + 255) / 256);
   const bool k_ok = g.K % (128 / (int)sizeof(T)) == 0;   // the 256 x 256 kernel moves 128 bytes of K per row and K-tile
-  if (k_ok && tile_mode() == 0 && tiles256 < 128 && tiles256 * 2 <= n_cus()) {
+  // (column sums come out of the single-pass epilogues only: no K spans for a problem that wants them)
+  if (k_ok && tile_mode() == 0 && tiles256 < 128 && tiles256 * 2 <= n_cus() && !g.colsum) {
     const int sp = pick_spans(g, tiles256, g.K / (128 / (int)sizeof(T)));
     if (sp > 1) {
       if constexpr (sizeof(T) == 2) {
@@ -585,7 +586,7 @@ int dispatch(const GemmArgs<T>& g, int epi, hipStream_t s) {
       // a tail of several hundred rows (M = 3328, N = 6144: 768 rows) is one well-filled round of the 128 x 256 kernel
       // (144 tiles) instead of 288 ring-kernel tiles: 35 -> 27 us
       if (tail_fits128<T>(tail.M, tail.N)) return half_height_bf16(tail, epi, s);
-      const int sp = pick_tail_spans(tail);
+      const int sp = g.colsum ? 1 : pick_tail_spans(tail);
       if (sp > 1) {
         GemmArgs<T> part = tail;                    // pass 1: raw fp32 partial tiles of the tail rows, [sp][tail.M][N]
         part.bias = nullptr; part.aux = nullptr; part.C = split_ws().ptr; part.ldc = g.N; part.ksplit = sp;
@@ -752,6 +753,12 @@ extern "C" int gpt_gemm_nt_static(int dtype, const void* A, int64_t lda, const v
 extern "C" int gpt_gemm_nt(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                            void* C, int64_t ldc, void* aux, int64_t ldaux, int M, int N, int K, int epilogue,
                            void* stream) {
+  return gpt_gemm_nt_colsum(dtype, A, lda, W, ldw, bias, C, ldc, aux, ldaux, M, N, K, epilogue, nullptr, stream);
+}
+
+int gpt_gemm_nt_colsum(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc,
+                       void* aux, int64_t ldaux, int M, int N, int K, int epilogue, float* colsum, void* stream) {
+  GPT_REQUIRE(!colsum || epilogue == GPT_EPI_DGELU, "gpt_gemm_nt: column sums exist for the DGELU epilogue only");
   GPT_REQUIRE(dtype == GPT_F32 || dtype == GPT_BF16, "gpt_gemm_nt: bad dtype %d", dtype);
   GPT_REQUIRE(M > 0 && N > 0 && K > 0, "gpt_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
   const int esz = dtype == GPT_BF16 ? 2 : 4;
@@ -769,8 +776,10 @@ extern "C" int gpt_gemm_nt(int dtype, const void* A, int64_t lda, const void* W,
   hipStream_t s = (hipStream_t)stream;
   if (dtype == GPT_BF16) {
     GemmArgs<bf16_t> g{(const bf16_t*)A, (const bf16_t*)W, bias, C, aux, lda, ldw, ldc, ldaux, M, N, K};
+    g.colsum = colsum;
     return dispatch<bf16_t>(g, epilogue, s);
   }
   GemmArgs<float> g{(const float*)A, (const float*)W, bias, C, aux, lda, ldw, ldc, ldaux, M, N, K};
+  g.colsum = colsum;
   return dispatch<float>(g, epilogue, s);
 }

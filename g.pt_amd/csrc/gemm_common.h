@@ -19,6 +19,9 @@ struct GemmArgs {
   // K spans (gemm256 only, GPT_EPI_STORE_F32 into a workspace): workgroup (span, tile) contracts K-tiles
   // [span * ceil(nk / ksplit), ...) and stores its partial tile at C + span * M * ldc
   int ksplit = 1;
+  // GPT_EPI_DGELU only: += the column sums of the output (the bias gradient of the Linear whose output gradient this GEMM
+  // produces: its separate colsum pass reads the whole [M, 4d] matrix again), fp32 atomics, one per column and wave; or NULL
+  float* colsum = nullptr;
 };
 
 template <typename T>
@@ -210,6 +213,36 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs<T>& g, ToPatch&& to
   // the bias is consumed HERE as far as the compiler can tell: otherwise its first use sits inside the steps below and
   // hipcc's wait for it (s_waitcnt vmcnt(0), repeated after every branch) drains the stores of every step
   asm volatile("" : "+v"(b0.x), "+v"(b0.y), "+v"(b0.z), "+v"(b0.w), "+v"(b1.x), "+v"(b1.y), "+v"(b1.z), "+v"(b1.w));
+  // column sums of the stored values (GemmArgs::colsum): this lane's 8 columns over the rows it handles
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool want_cs = EPI == GPT_EPI_DGELU && g.colsum != nullptr;                 // workgroup-uniform
+  auto store_rows = [&](int m, const float4& x0, const float4& x1, const EpiPre& pre) {
+    if constexpr (EPI == GPT_EPI_DGELU) {
+      const float4 o0 = dgelu4<T>(x0, pre.a), o1 = dgelu4<T>(x1, pre.b);
+      store8<T>((T*)g.C + (int64_t)m * g.ldc + n, o0, o1);
+      if (want_cs) {
+        cs[0] += o0.x; cs[1] += o0.y; cs[2] += o0.z; cs[3] += o0.w;
+        cs[4] += o1.x; cs[5] += o1.y; cs[6] += o1.z; cs[7] += o1.w;
+      }
+    } else {
+      epi_store8<T, EPI>(g, m, n, x0, x1, pre);
+    }
+  };
+  auto flush_cs = [&]() {
+    if constexpr (EPI == GPT_EPI_DGELU) {
+      if (!want_cs) return;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        cs[j] += __shfl_xor(cs[j], 8, 64);
+        cs[j] += __shfl_xor(cs[j], 16, 64);
+        cs[j] += __shfl_xor(cs[j], 32, 64);
+      }
+      if (pr == 0 && n < g.N) {                    // lanes 0..7: one hardware float atomic per column (N % 8 == 0)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) unsafeAtomicAdd(g.colsum + n + j, cs[j]);
+      }
+    }
+  };
   // wave-uniform: the wave's whole (32 NI) x 64 block lies inside the matrix -> straight-line code, counted waits
   const bool full = __builtin_amdgcn_readfirstlane((mrow0 + ROWS <= g.M && ncol0 + 64 <= g.N) ? 1 : 0) != 0;
   if (full) {
@@ -235,10 +268,11 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs<T>& g, ToPatch&& to
         const int row = p * 8 + pr;
         const float4 v0 = *reinterpret_cast<const float4*>(patch + row * PATCH_PITCH + pc8);
         const float4 v1 = *reinterpret_cast<const float4*>(patch + row * PATCH_PITCH + pc8 + 4);
-        epi_store8<T, EPI>(g, mrow0 + i * 32 + row, n, add4(v0, b0), add4(v1, b1), pre[i & 1][p]);
+        store_rows(mrow0 + i * 32 + row, add4(v0, b0), add4(v1, b1), pre[i & 1][p]);
       }
       WAVE_LDS_ORDER();
     }
+    flush_cs();
     return;
   }
   // edge tiles: per-lane bounds
@@ -256,11 +290,12 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs<T>& g, ToPatch&& to
       if (m < g.M && n < g.N) {
         EpiPre pre;
         if constexpr (epi_reads<EPI>) epi_load8<T, EPI>(g, m, n, pre);
-        epi_store8<T, EPI>(g, m, n, add4(v0, b0), add4(v1, b1), pre);
+        store_rows(m, add4(v0, b0), add4(v1, b1), pre);
       }
     }
     WAVE_LDS_ORDER();
   }
+  flush_cs();
 }
 
 // Optional per-launch timing with HIP events recorded on the launch stream (bench.py roofline pass).

@@ -214,6 +214,10 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
     const char* e = getenv("GPT_WGRAD_TN");   // 0: always transpose + NT kernel (cross-check of the TN kernel)
     return !e || atoi(e) != 0;
   }();
+  static const bool fuse_b1 = [] {
+    const char* e = getenv("GPT_DGELU_COLSUM");   // 0: mlp.0's bias gradient by a separate gpt_colsum launch (cross-check, A/B)
+    return !e || atoi(e) != 0;
+  }();
   static const bool fuse_col = [] {
     const char* e = getenv("GPT_LNB_COLSUM");   // 0: bias gradients of mlp.2 / attn.proj by separate gpt_colsum launches (cross-check, A/B)
     return !e || atoi(e) != 0;
@@ -301,9 +305,11 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
     // mlp.2
     if (!fuse_col) CHECK(gpt_colsum(dt, gt_l, d, gl.g_b2, M, d, stream));
     if (!grouped) CHECK(wgrad(gt_l, d, act, 4 * d, gl.g_w2));
-    CHECK(gpt_gemm_nt(dt, gt_l, d, gl.w2_t, d, nullptr, d_act_l, 4 * d, pre, 4 * d, M, 4 * d, d, GPT_EPI_DGELU, stream));
+    // ... and mlp.0's bias gradient = the column sums of that output, taken in the same epilogue
+    CHECK(gpt_gemm_nt_colsum(dt, gt_l, d, gl.w2_t, d, nullptr, d_act_l, 4 * d, pre, 4 * d, M, 4 * d, d, GPT_EPI_DGELU,
+                             fuse_b1 ? gl.g_b1 : nullptr, stream));
     // mlp.0
-    CHECK(gpt_colsum(dt, d_act_l, 4 * d, gl.g_b1, M, 4 * d, stream));
+    if (!fuse_b1) CHECK(gpt_colsum(dt, d_act_l, 4 * d, gl.g_b1, M, 4 * d, stream));
     if (!grouped) CHECK(wgrad(d_act_l, 4 * d, h2, d, gl.g_w1));
     CHECK(gpt_gemm_nt(dt, d_act_l, 4 * d, gl.w1_t, 4 * d, nullptr, bw->d_h, d, nullptr, 0, M, d, 4 * d, GPT_EPI_STORE, stream));
     CHECK(gpt_layernorm_bwd_colsum(bw->d_h, dt, xbuf(2 * l + 1), stat(2 + 2 * l, 0), stat(2 + 2 * l, 1), ly.ln2_w, bw->g, bw->g, gt2, dt,
