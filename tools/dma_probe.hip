@@ -28,7 +28,9 @@ __device__ __forceinline__ void wait_vm() {
 }
 
 // WAVES = waves of the 8 that issue (each issues 64 / WAVES pieces per K-tile); DEPTH = K-tiles kept in flight
-template <int WAVES, int DEPTH>
+// SEG = 0: pieces of 8 rows x 128 bytes (whole lines);  1: pieces of 16 rows x 64 bytes, the two halves of a line 16 pieces apart
+// (the fill shape of a ring of 32-wide k-slots: gemm256w.hip);  2: the same half-line pieces, both halves of a line by consecutive pieces
+template <int WAVES, int DEPTH, int SEG = 0>
 __global__ __launch_bounds__(512, 2) void probe(const unsigned short* __restrict__ A, const unsigned short* __restrict__ W, int64_t lda,
                                                 int64_t ldw, int M, int N, int nk, unsigned long long* cyc, unsigned int* sink) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -52,8 +54,13 @@ __global__ __launch_bounds__(512, 2) void probe(const unsigned short* __restrict
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
       const int gp = wid * PPW + j;
-      const int row = (gp & 31) * 8 + (lane >> 3);
-      const int lc = (lane & 7) ^ ((row >> 1) & 7);
+      int row = (gp & 31) * 8 + (lane >> 3);
+      int lc = (lane & 7) ^ ((row >> 1) & 7);
+      if (SEG) {
+        const int idx = gp & 31, half = SEG == 1 ? idx >> 4 : idx & 1, rg = SEG == 1 ? idx & 15 : idx >> 1;
+        row = rg * 16 + (lane >> 2);
+        lc = ((lane & 3) ^ ((row >> 3) & 3)) + 4 * half;
+      }
       src[j] = gp < 32 ? A + (int64_t)(m0 + row) * lda + lc * 8 : W + (int64_t)(n0 + row) * ldw + lc * 8;
     }
     for (int kt = 0; kt < nk; kt += DEPTH) {
@@ -76,10 +83,10 @@ __global__ __launch_bounds__(512, 2) void probe(const unsigned short* __restrict
   if (tid == 0) cyc[bid] = __builtin_amdgcn_s_memtime() - t0;
 }
 
-template <int WAVES, int DEPTH>
+template <int WAVES, int DEPTH, int SEG = 0>
 void run(const char* name, const unsigned short* A, const unsigned short* W, int M, int N, int K, unsigned long long* cyc, unsigned int* sink) {
   const int tiles = (M / 256) * (N / 256), nk = K / 64;
-  CHECK(hipFuncSetAttribute((const void*)probe<WAVES, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+  CHECK(hipFuncSetAttribute((const void*)probe<WAVES, DEPTH, SEG>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
@@ -87,7 +94,7 @@ void run(const char* name, const unsigned short* A, const unsigned short* W, int
   for (int it = 0; it < 2; ++it) {
     if (it == 1) CHECK(hipEventRecord(e0, 0));
     for (int i = 0; i < (it ? reps : 2); ++i)
-      hipLaunchKernelGGL((probe<WAVES, DEPTH>), dim3(tiles), dim3(512), 131072, 0, A, W, (int64_t)K, (int64_t)K, M, N, nk, cyc, sink);
+      hipLaunchKernelGGL((probe<WAVES, DEPTH, SEG>), dim3(tiles), dim3(512), 131072, 0, A, W, (int64_t)K, (int64_t)K, M, N, nk, cyc, sink);
   }
   CHECK(hipEventRecord(e1, 0));
   CHECK(hipEventSynchronize(e1));
@@ -126,6 +133,9 @@ int main() {
     run<8, 7>("lds-dma 8 waves depth 7", A, W, M, N, K, cyc, sink);
     run<4, 2>("lds-dma 4 waves depth 2", A, W, M, N, K, cyc, sink);
     run<4, 3>("lds-dma 4 waves depth 3", A, W, M, N, K, cyc, sink);
+    run<4, 3, 1>("half lines 16 apart, 4 waves d3", A, W, M, N, K, cyc, sink);
+    run<4, 3, 2>("half lines adjacent, 4 waves d3", A, W, M, N, K, cyc, sink);
+    run<8, 4, 1>("half lines 16 apart, 8 waves d4", A, W, M, N, K, cyc, sink);
   }
   return 0;
 }

@@ -1,18 +1,11 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 1500 python -u -m pytest tests -x -q -m gpu --timeout 300 --timeout-method thread > gpurun_out/r2_gpu_all.log 2>&1; rc=$?; tail -3 gpurun_out/r2_gpu_all.log | cut -c1-300
-if grep -q "HSA_STATUS_ERROR\|Memory access fault" gpurun_out/r2_gpu_all.log; then echo FAULT; exit 1; fi
-[ $rc -eq 0 ] || exit $rc
-timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1 || { tail -5 gpurun_out/smoke.log; exit 1; }
-tail -1 gpurun_out/smoke.log
-timeout -k 10 900 python bench.py > gpurun_out/r2_bench6.json 2> gpurun_out/r2_bench6.err || { tail -5 gpurun_out/r2_bench6.err; exit 1; }
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r2_bench6.json').read().strip().splitlines()[-1])
-print({k:d[k] for k in ('value','ms_per_step')}, 'frac', d['roofline']['frac'])
-for k in ('fp32','cifar','train','train_weak'):
-    o=d.get(k); 
-    if o: print(k,{kk:(o[kk] if kk!='roofline' else o[kk]['frac']) for kk in o if kk in ('value','ms_per_step','roofline','error')})
-PY
-bash tools/profile_r02.sh > gpurun_out/profile_r02.log 2>&1 || { tail -5 gpurun_out/profile_r02.log; exit 1; }
-grep "GPU busy" gpurun_out/profile_r02.log
+L=$PWD/g.pt_amd/lib
+GPT_HIP_LIB=$L/libgpt_hip_agpr.so timeout -k 10 300 python -u -m pytest tests/test_hip_parity.py -x -q -m gpu -k "gemm" --timeout 120 --timeout-method thread > gpurun_out/agpr_parity.log 2>&1 || { tail -15 gpurun_out/agpr_parity.log; exit 1; }
+tail -1 gpurun_out/agpr_parity.log
+for rep in 1 2; do
+echo "== base";      timeout -k 10 120 python tools/gemm_bench.py 2>/dev/null || exit 1
+echo "== agpr";      GPT_HIP_LIB=$L/libgpt_hip_agpr.so timeout -k 10 120 python tools/gemm_bench.py 2>/dev/null || exit 1
+done
+echo "== base abl7"; GPT_HIP_LIB=$L/libgpt_hip_abl7.so timeout -k 10 120 python tools/gemm_bench.py --shapes sq8192:8192:8192:8192 2>/dev/null || exit 1
+echo "== agpr abl7"; GPT_HIP_LIB=$L/libgpt_hip_agpr_abl7.so timeout -k 10 120 python tools/gemm_bench.py --shapes sq8192:8192:8192:8192 2>/dev/null || exit 1
