@@ -52,13 +52,21 @@ class TrainStep:
     configure_optimizers, accumulate) over the same gradient arena - the cross-check of the fused pass."""
 
     def __init__(self, model, diffusion, lr=4e-4, wd=0.1, betas=(0.9, 0.999), eps=1e-8, grad_clip=0.75, ema_decay=0.9999,
-                 use_ema=True, bucket_layers=None, fused=True, overlap=True, shard=None, grad_payload=None):
+                 use_ema=True, bucket_layers=None, fused=True, overlap=True, shard=None, grad_payload=None,
+                 overlap_update=None):
         self.model, self.diffusion = model, diffusion
         self.device = model.decoder.pos_emb.device
         self.lr, self.wd, self.betas, self.eps = lr, wd, betas, eps
         self.grad_clip, self.ema_decay, self.fused, self.overlap = grad_clip, ema_decay, fused, overlap
         self._handles = []
         self._side, self._t_ready = None, None
+        # the Blocks' share of the optimizer pass on a side stream, layer by layer, beside the NEXT step's forward (see update());
+        # opt-in (GPT_OPT_OVERLAP=1): whoever reads parameters, EMA or operands other than through this engine's forward or
+        # state_dict() has to call join() first
+        if overlap_update is None:
+            overlap_update = os.environ.get("GPT_OPT_OVERLAP", "0") != "0"
+        self.overlap_update = bool(overlap_update and fused)
+        self._opt_done = None
         self.world = dp.get_world_size()
         self.flat = FlatState(model, self.device)
         if dp.exchanging():                             # rank 0's weights everywhere (DDP construction, main.py:231-236)
@@ -99,8 +107,18 @@ class TrainStep:
         self.buckets = self._make_buckets(bucket_layers)
         if self.shard:
             self._init_shards()
+        elif self.overlap_update:
+            self.model.register_state_dict_pre_hook(lambda *a, **k: self.join())
+            if self.ema is not None:
+                self.ema.register_state_dict_pre_hook(lambda *a, **k: self.join())
         self.tmap = torch.tensor(diffusion._timestep_map(), device=self.device, dtype=torch.long)
         self.iteration = 0
+
+    def join(self):
+        """Makes the current stream wait for an optimizer pass still running on the side stream (overlap_update)."""
+        if self._opt_done is not None:
+            torch.cuda.current_stream().wait_event(self._opt_done)
+            self._opt_done = None
 
     def _make_buckets(self, bucket_layers):
         """Contiguous arena ranges (lo, hi, stage_end, region), in the order the backward finishes them (complete once the
@@ -310,7 +328,7 @@ class TrainStep:
         packed = self.flat.packed(self.code)
         ema = self.flat_ema.params if self.flat_ema is not None else None
 
-        def adamw(lo, count, grads, m_off, seg, n_seg, zero_grad):
+        def adamw(lo, count, grads, m_off, seg, n_seg, zero_grad, st=st):
             """The fused pass over arena elements [lo, lo + count); moments at m_off of the moment buffers."""
             L.check(lib.gpt_adamw_ema_step(
                 L.ptr(self.flat.params[lo:]), L.ptr(grads), L.ptr(self.exp_avg[m_off:]), L.ptr(self.exp_avg_sq[m_off:]),
@@ -333,8 +351,32 @@ class TrainStep:
                 if not hasattr(self, "_seg_split"):
                     self._seg_split = (self.flat.segment_table(self.code, 0, cut), self.flat.segment_table(self.code, cut, n))
                 (sa, na), (sb, nb) = self._seg_split
-                adamw(0, cut, self.grads, 0, sa, na, 0)
-                adamw(cut, n - cut, self.grads[cut:], cut, sb, nb, 1)
+                if self.overlap_update:
+                    # The optimizer pass is HBM-bound (38 bytes per parameter, 2.4 ms for the Blocks' weights at the mnist
+                    # shapes) and the forward MFMA-bound: the Blocks' share runs on the side stream one layer at a time, each
+                    # followed by an event the NEXT forward waits for right before that block (gpt_layer_t.ready, as for the
+                    # sharded step's operand gather); everything the encoder and the blocks' biases / LayerNorms need (region R
+                    # and the decoder Linears, 5 % of the arena) is updated on the compute stream first.  The next backward
+                    # waits for the whole side stream (_t_ready below) before it overwrites the gradients these launches read.
+                    adamw(cut, n - cut, self.grads[cut:], cut, sb, nb, 1)
+                    starts = list(self.arena.s_layer_start) + [cut]
+                    if not hasattr(self, "_seg_layers"):
+                        self._seg_layers = [self.flat.segment_table(self.code, starts[l], starts[l + 1]) for l in range(len(starts) - 1)]
+                        self._layer_events = [torch.cuda.Event() for _ in self._seg_layers]
+                    main = torch.cuda.current_stream()
+                    if self._side is None:
+                        self._side = torch.cuda.Stream(device=self.device)
+                    self._side.wait_stream(main)
+                    with torch.cuda.stream(self._side):
+                        sst = L.stream()
+                        for l, ((sl, nl), ev) in enumerate(zip(self._seg_layers, self._layer_events)):
+                            adamw(starts[l], starts[l + 1] - starts[l], self.grads[starts[l]:], starts[l], sl, nl, 0, st=sst)
+                            ev.record(self._side)
+                    self._opt_done = self._side.record_event()
+                    self.eng.set_ready(list(self._layer_events), None)
+                else:
+                    adamw(0, cut, self.grads, 0, sa, na, 0)
+                    adamw(cut, n - cut, self.grads[cut:], cut, sb, nb, 1)
             else:
                 seg, n_seg = self.flat.segments(self.code)
                 adamw(0, n, self.grads, 0, seg, n_seg, 1)
@@ -430,7 +472,10 @@ def bench_train(args, device, world, rank):
     if case == "cifar_big":
         c = CASES[case]
         cfg_name += f" with a scaled-up transformer (n_embd {c['n_embd']}, {c['n_head']} heads, {c['n_layer']} layers)"
-    ts = TrainStep(model, diff, lr=4e-4, wd=0.1, betas=(0.9, 0.999), grad_clip=clip, ema_decay=0.9999)
+    # the training loop proper: nothing reads parameters between steps, so the Blocks' optimizer pass may run beside the next
+    # forward (GPT_OPT_OVERLAP=0 for A/B)
+    ts = TrainStep(model, diff, lr=4e-4, wd=0.1, betas=(0.9, 0.999), grad_clip=clip, ema_decay=0.9999,
+                   overlap_update=os.environ.get("GPT_OPT_OVERLAP", "1") != "0")
     batches = [synthetic_pairs(case, B, device, seed=1000 * rank + i) for i in range(4)]
     iters_per_epoch = 1000
     augment = getattr(args, "augment", False)

@@ -289,6 +289,48 @@ def test_store_mode_weight_gradients_equal_accumulation(monkeypatch):
     assert not ts._overwrote and float(ts.grads.abs().max()) == 0.0
 
 
+@pytest.mark.gpu
+def test_overlapped_optimizer_pass_equals_the_in_order_one():
+    """overlap_update: the Blocks' share of the fused AdamW + EMA pass runs on a side stream, layer by layer, beside the next
+    step's forward, which waits per block (gpt_layer_t.ready).  Four steps must give the parameters and the EMA of the in-order
+    step (elementwise pass cut at layer boundaries: the only differences are those of the atomically summed gradients), read
+    through state_dict(), whose hook joins the side stream."""
+    from gpt_amd.trainstep import TrainStep
+    diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
+    runs = []
+    for flag in (True, False):
+        m, plan, sd = build("cifar_small", "bf16", seed=4)
+        m.train()
+        ts = TrainStep(m, diff, lr=1e-3, wd=0.1, grad_clip=0.75, overlap_update=flag)
+        for i in range(4):
+            _, _, lt, lp, xp = (v.to(DEV) for v in make_inputs("cifar_small", B=32, seed=150 + i))
+            gen = torch.Generator().manual_seed(170 + i)
+            x1 = xp + 0.1 * torch.randn(xp.shape, generator=gen).to(DEV)
+            t = torch.randint(0, 1000, (32,), generator=gen).to(DEV)
+            noise = torch.randn(xp.shape, generator=gen).to(DEV)
+            ts.step(xp, x1, lp, lt, t, noise=noise)
+        assert ts._overwrote and (ts._opt_done is not None) == flag
+        got = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+        got.update({"ema." + k: v.detach().float().cpu() for k, v in ts.ema.state_dict().items()})
+        assert ts._opt_done is None                       # the state_dict hooks joined
+        # the engine's operand copies were written by the same launches: a forward through them must see the new weights
+        x, tm, lt2, lp2, xp2 = (v.to(DEV) for v in make_inputs("cifar_small", B=8, seed=9))
+        with torch.no_grad():
+            got["_out"] = m.eval()(x, tm, lt2, lp2, xp2).float().cpu()
+        runs.append(got)
+    for k in runs[0]:
+        if k.endswith("attn.key.bias"):
+            continue
+        dk = (runs[0][k] - runs[1][k]).abs()
+        if k == "_out":
+            # a bf16 forward through weights that agree to the bars below (their bf16 roundings may differ by an ulp); a forward
+            # through the operands of a step earlier would be off by the four steps' lr = 4e-3 in every weight
+            assert float(dk.max()) < 1e-2 and float(dk.mean()) < 1e-3, (float(dk.max()), float(dk.mean()))
+            continue
+        assert float(dk.max()) < 5e-4 * max(1.0, float(runs[1][k].abs().max())), k
+        assert float(dk.mean()) < 1e-5 * max(1.0, float(runs[1][k].abs().mean())), k
+
+
 # ---------------------------------------------------------------------------------------------- data parallel
 def _ddp_rank(rank, world, port, out_path, mode="replicated", dtype="fp32"):
     """One rank of a 2-process data-parallel step; both ranks use GPU 0 (the box has one), so the exchange runs on gloo.

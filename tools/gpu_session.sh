@@ -1,11 +1,14 @@
 set -o pipefail
 mkdir -p gpurun_out
-L=$PWD/g.pt_amd/lib
-GPT_HIP_LIB=$L/libgpt_hip_agpr.so timeout -k 10 300 python -u -m pytest tests/test_hip_parity.py -x -q -m gpu -k "gemm" --timeout 120 --timeout-method thread > gpurun_out/agpr_parity.log 2>&1 || { tail -15 gpurun_out/agpr_parity.log; exit 1; }
-tail -1 gpurun_out/agpr_parity.log
+python -c "import torch; print(torch.cuda.Stream.priority_range())"
 for rep in 1 2; do
-echo "== base";      timeout -k 10 120 python tools/gemm_bench.py 2>/dev/null || exit 1
-echo "== agpr";      GPT_HIP_LIB=$L/libgpt_hip_agpr.so timeout -k 10 120 python tools/gemm_bench.py 2>/dev/null || exit 1
+for h in 0 1; do
+  for b in 128 1024; do
+    GPT_TRAIN_HIPRIO=$h timeout -k 10 300 python bench.py --mode train --batch $b --steps 40 --warmup 10 --no-cpu-baseline --no-roofline > gpurun_out/ovl_b.json 2> gpurun_out/ovl_b.err || { tail -5 gpurun_out/ovl_b.err; exit 1; }
+    python -c "
+import json
+d=json.loads(open('gpurun_out/ovl_b.json').read().strip().splitlines()[-1])
+print('hiprio',$h,'batch',$b,'ms',round(d['ms_per_step'],3),'loss',d.get('final_loss'))"
+  done
 done
-echo "== base abl7"; GPT_HIP_LIB=$L/libgpt_hip_abl7.so timeout -k 10 120 python tools/gemm_bench.py --shapes sq8192:8192:8192:8192 2>/dev/null || exit 1
-echo "== agpr abl7"; GPT_HIP_LIB=$L/libgpt_hip_agpr_abl7.so timeout -k 10 120 python tools/gemm_bench.py --shapes sq8192:8192:8192:8192 2>/dev/null || exit 1
+done
