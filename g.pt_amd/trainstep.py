@@ -233,6 +233,7 @@ class TrainStep:
     @torch.no_grad()
     def sync_params(self):
         """fp32 parameters of the other ranks' shards (bf16 compute mode gathers only the bf16 operands per step)."""
+        self.join()
         if self.shard:
             self._wait_operands()
             if self._params_stale:
@@ -240,6 +241,7 @@ class TrainStep:
 
     @torch.no_grad()
     def sync_ema(self):
+        self.join()
         if self.shard and self._ema_stale and self.flat_ema is not None:
             self._gather(self.flat_ema.params, "_ema_stale")
 
