@@ -1,8 +1,5 @@
 set -o pipefail
 mkdir -p gpurun_out
-SH="--rounds 40 --shapes fc1:8320:6144:1536:1 fc1d:8320:6144:1536:0"
-for rep in 1 2; do
-for k in 0 4 6 8; do
-  echo "== tail128k=$k"; GPT_GEMM_TAIL128K=$k timeout -k 10 120 python tools/gemm_bench.py $SH 2>/dev/null || exit 1
-done
-done
+timeout -k 10 900 python -u -m pytest tests/test_hip_training.py tests/test_zz_no_alloc.py -x -q -m gpu --timeout 300 --timeout-method thread > gpurun_out/train_tests.log 2>&1; rc=$?; tail -3 gpurun_out/train_tests.log | cut -c1-300
+if grep -q "HSA_STATUS_ERROR\|Memory access fault" gpurun_out/train_tests.log; then echo FAULT; exit 1; fi
+exit $rc
