@@ -347,38 +347,40 @@ class TrainStep:
             elif self.grad_clip > 0:
                 L.check(lib.gpt_grad_sumsq(L.ptr(self.grads), n, L.ptr(self.norm_scratch), L.ptr(self.grad_norm_sq), st),
                         "gpt_grad_sumsq")
-            if getattr(self, "_overwrote", False):
-                # block weights: nothing to zero (the next backward overwrites them); the rest still accumulates
-                cut = self.arena.s_dec_start
+            overwrote = getattr(self, "_overwrote", False)
+            cut = self.arena.s_dec_start
+            if overwrote or self.overlap_update:
                 if not hasattr(self, "_seg_split"):
                     self._seg_split = (self.flat.segment_table(self.code, 0, cut), self.flat.segment_table(self.code, cut, n))
                 (sa, na), (sb, nb) = self._seg_split
-                if self.overlap_update:
-                    # The optimizer pass is HBM-bound (38 bytes per parameter, 2.4 ms for the Blocks' weights at the mnist
-                    # shapes) and the forward MFMA-bound: the Blocks' share runs on the side stream one layer at a time, each
-                    # followed by an event the NEXT forward waits for right before that block (gpt_layer_t.ready, as for the
-                    # sharded step's operand gather); everything the encoder and the blocks' biases / LayerNorms need (region R
-                    # and the decoder Linears, 5 % of the arena) is updated on the compute stream first.  The next backward
-                    # waits for the whole side stream (_t_ready below) before it overwrites the gradients these launches read.
-                    adamw(cut, n - cut, self.grads[cut:], cut, sb, nb, 1)
-                    starts = list(self.arena.s_layer_start) + [cut]
-                    if not hasattr(self, "_seg_layers"):
-                        self._seg_layers = [self.flat.segment_table(self.code, starts[l], starts[l + 1]) for l in range(len(starts) - 1)]
-                        self._layer_events = [torch.cuda.Event() for _ in self._seg_layers]
-                    main = torch.cuda.current_stream()
-                    if self._side is None:
-                        self._side = torch.cuda.Stream(device=self.device)
-                    self._side.wait_stream(main)
-                    with torch.cuda.stream(self._side):
-                        sst = L.stream()
-                        for l, ((sl, nl), ev) in enumerate(zip(self._seg_layers, self._layer_events)):
-                            adamw(starts[l], starts[l + 1] - starts[l], self.grads[starts[l]:], starts[l], sl, nl, 0, st=sst)
-                            ev.record(self._side)
-                    self._opt_done = self._side.record_event()
-                    self.eng.set_ready(list(self._layer_events), None)
-                else:
-                    adamw(0, cut, self.grads, 0, sa, na, 0)
-                    adamw(cut, n - cut, self.grads[cut:], cut, sb, nb, 1)
+            # store mode: nothing to zero in the Blocks' weights (the next backward overwrites them); the rest still accumulates
+            zero_blocks = 0 if overwrote else 1
+            if self.overlap_update:
+                # The optimizer pass is HBM-bound (38 - 42 bytes per parameter, 2.4 ms for the Blocks' weights at the mnist
+                # shapes) and the forward MFMA-bound: the Blocks' share runs on the side stream one layer at a time, each
+                # followed by an event the NEXT forward waits for right before that block (gpt_layer_t.ready, as for the
+                # sharded step's operand gather); everything the encoder and the blocks' biases / LayerNorms need (region R
+                # and the decoder Linears, 5 % of the arena) is updated on the compute stream first.  The next backward
+                # waits for the whole side stream (_t_ready below) before it writes the gradients these launches read / zero.
+                adamw(cut, n - cut, self.grads[cut:], cut, sb, nb, 1)
+                starts = list(self.arena.s_layer_start) + [cut]
+                if not hasattr(self, "_seg_layers"):
+                    self._seg_layers = [self.flat.segment_table(self.code, starts[l], starts[l + 1]) for l in range(len(starts) - 1)]
+                    self._layer_events = [torch.cuda.Event() for _ in self._seg_layers]
+                main = torch.cuda.current_stream()
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.device)
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    sst = L.stream()
+                    for l, ((sl, nl), ev) in enumerate(zip(self._seg_layers, self._layer_events)):
+                        adamw(starts[l], starts[l + 1] - starts[l], self.grads[starts[l]:], starts[l], sl, nl, zero_blocks, st=sst)
+                        ev.record(self._side)
+                self._opt_done = self._side.record_event()
+                self.eng.set_ready(list(self._layer_events), None)
+            elif overwrote:
+                adamw(0, cut, self.grads, 0, sa, na, 0)
+                adamw(cut, n - cut, self.grads[cut:], cut, sb, nb, 1)
             else:
                 seg, n_seg = self.flat.segments(self.code)
                 adamw(0, n, self.grads, 0, seg, n_seg, 1)
@@ -417,6 +419,7 @@ class TrainStep:
         # transposed dgrad operands of the new weights: needed by the NEXT backward only, so the 48 transposes run on a side
         # stream beside the next forward (memory-bound beside MFMA-bound; 0.9 ms of an 18 ms step at B = 128 otherwise)
         if os.environ.get("GPT_TRAIN_SIDE_STREAM", "1") == "0":      # A/B measurements
+            self.join()
             if self.shard:
                 self._wait_operands()
             _ensure_training_state(self.eng)

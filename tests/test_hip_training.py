@@ -290,26 +290,33 @@ def test_store_mode_weight_gradients_equal_accumulation(monkeypatch):
 
 
 @pytest.mark.gpu
-def test_overlapped_optimizer_pass_equals_the_in_order_one():
+@pytest.mark.parametrize("dtype,B,store", [("bf16", 32, True), ("bf16", 5, False), ("fp32", 8, False)])
+def test_overlapped_optimizer_pass_equals_the_in_order_one(dtype, B, store):
     """overlap_update: the Blocks' share of the fused AdamW + EMA pass runs on a side stream, layer by layer, beside the next
     step's forward, which waits per block (gpt_layer_t.ready).  Four steps must give the parameters and the EMA of the in-order
     step (elementwise pass cut at layer boundaries: the only differences are those of the atomically summed gradients), read
-    through state_dict(), whose hook joins the side stream."""
+    through state_dict(), whose hook joins the side stream; in store mode and in accumulate mode (a batch the grouped
+    weight-gradient launch does not take; fp32)."""
     from gpt_amd.trainstep import TrainStep
     diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
     runs = []
     for flag in (True, False):
-        m, plan, sd = build("cifar_small", "bf16", seed=4)
+        m, plan, sd = build("cifar_small", dtype, seed=4)
         m.train()
         ts = TrainStep(m, diff, lr=1e-3, wd=0.1, grad_clip=0.75, overlap_update=flag)
         for i in range(4):
-            _, _, lt, lp, xp = (v.to(DEV) for v in make_inputs("cifar_small", B=32, seed=150 + i))
+            _, _, lt, lp, xp = (v.to(DEV) for v in make_inputs("cifar_small", B=B, seed=150 + i))
             gen = torch.Generator().manual_seed(170 + i)
             x1 = xp + 0.1 * torch.randn(xp.shape, generator=gen).to(DEV)
-            t = torch.randint(0, 1000, (32,), generator=gen).to(DEV)
+            t = torch.randint(0, 1000, (B,), generator=gen).to(DEV)
             noise = torch.randn(xp.shape, generator=gen).to(DEV)
             ts.step(xp, x1, lp, lt, t, noise=noise)
-        assert ts._overwrote and (ts._opt_done is not None) == flag
+        # store mode (the Blocks' weight gradients overwritten, nothing to zero) and accumulate mode (zeroed by the same launches)
+        assert ts._overwrote == store and (ts._opt_done is not None) == flag
+        assert float(ts.grads[ts.arena.s_dec_start:].abs().max()) == 0.0
+        if not store:
+            torch.cuda.synchronize()
+            assert float(ts.grads.abs().max()) == 0.0
         got = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
         got.update({"ema." + k: v.detach().float().cpu() for k, v in ts.ema.state_dict().items()})
         assert ts._opt_done is None                       # the state_dict hooks joined
