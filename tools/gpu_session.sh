@@ -1,13 +1,16 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 600 python -u -m pytest tests/test_hip_training.py -x -q -m gpu -k "overlapped_optimizer or store_mode or fused_step or golden" --timeout 120 --timeout-method thread > gpurun_out/ovl_test.log 2>&1 || { tail -30 gpurun_out/ovl_test.log; exit 1; }
-tail -1 gpurun_out/ovl_test.log
-for args in "--case cifar_big --batch 68 --augment" "--case mnist --batch 96 --dtype fp32" "--case mnist --batch 100"; do
-  for o in 0 1; do
-    GPT_OPT_OVERLAP=$o timeout -k 10 300 python bench.py --mode train $args --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > gpurun_out/t.json 2> gpurun_out/t.err || { tail -5 gpurun_out/t.err; exit 1; }
-    python -c "
+timeout -k 10 1500 python -u -m pytest tests -x -q -m gpu --timeout 300 --timeout-method thread > gpurun_out/r2_gpu_all.log 2>&1; rc=$?; tail -3 gpurun_out/r2_gpu_all.log | cut -c1-300
+if grep -q "HSA_STATUS_ERROR\|Memory access fault" gpurun_out/r2_gpu_all.log; then echo FAULT; exit 1; fi
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1 || { tail -5 gpurun_out/smoke.log; exit 1; }
+tail -1 gpurun_out/smoke.log
+timeout -k 10 900 python bench.py > gpurun_out/r2_bench8.json 2> gpurun_out/r2_bench8.err || { tail -5 gpurun_out/r2_bench8.err; exit 1; }
+python - <<'PY'
 import json
-d=json.loads(open('gpurun_out/t.json').read().strip().splitlines()[-1])
-print('$args', 'overlap', $o, 'ms', round(d['ms_per_step'],3), 'loss', d.get('final_loss'))"
-  done
-done
+d=json.loads(open('gpurun_out/r2_bench8.json').read().strip().splitlines()[-1])
+print({k:d[k] for k in ('value','ms_per_step')}, 'frac', d['roofline']['frac'])
+for k in ('fp32','cifar','train','train_weak'):
+    o=d.get(k); 
+    if o: print(k,{kk:(o[kk] if kk!='roofline' else o[kk]['frac']) for kk in o if kk in ('value','ms_per_step','roofline','error')})
+PY
