@@ -45,42 +45,15 @@ __device__ __forceinline__ float4 load4(const T* p) {
                        __uint_as_float(o.y & 0xffff0000u));
   }
 }
-// fp32 mode: libm erff (parity).  bf16 mode: Abramowitz-Stegun 7.1.26 (|erf error| < 1.5e-7, far below bf16's
-// 2^-9 output rounding) with the raw v_rcp_f32 / v_exp_f32 (1 ulp each): ~16 VALU per element instead of erff's ~40.
-// (__frcp_rn expands to the full IEEE division sequence, ~10 instructions: it made the GELU epilogue 40 k cycles.)
-__device__ __forceinline__ float erf_fast(float x) {
-  // z' = |x| sqrt(log2 e) / sqrt 2, so that exp(-z^2) = exp2(-z'^2); 0.3275911 z = P1 z'
-  constexpr float C = 0.84932180028801904272f, P1 = 0.3275911f / 1.20112240878645f;
-  const float zp = fabsf(x) * C;
-  const float t = __builtin_amdgcn_rcpf(fmaf(P1, zp, 1.0f));
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float erf_abs = fmaf(-poly, __builtin_amdgcn_exp2f(-zp * zp), 1.0f);
-  return copysignf(erf_abs, x);
-}
 // bf16 forward GELU: x * sigmoid(a x + b x^3 + c x^5), coefficients fitted (minimax over [-8, 8]) to the EXACT erf GELU of
 // nn.GELU(): |error| <= 2.6e-5 absolute, i.e. below half a bf16 ulp of the result wherever |gelu| >= 0.013 and below the
-// bf16 rounding of the activations it is summed with elsewhere.  11 VALU issue slots per element against 16 for the erf
-// form above (the GELU epilogue is VALU-bound: 128 elements per lane after every tile).  fp32 mode: libm erff.
-__device__ __forceinline__ float gelu_fast(float x) {
-  // -log2(e) * (a, b, c): sigmoid(p) = 1 / (1 + exp2(-log2(e) p))
-  constexpr float A = -1.5950157686361435f * 1.4426950408889634f, B = -0.07401129203229191f * 1.4426950408889634f,
-                  Cc = 0.000703033580348536f * 1.4426950408889634f;
-  const float xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);   // the fit's range: beyond it sigmoid is 0 / 1 to fp32 anyway
-  const float x2 = xc * xc;
-  const float q = xc * fmaf(x2, fmaf(x2, Cc, B), A);
-  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(q));
-}
-// d/dx gelu(x) = Phi(x) + x phi(x), same approximation (bf16 training mode)
-__device__ __forceinline__ float gelu_fast_grad(float x) {
-  const float cdf = fmaf(0.5f, erf_fast(x), 0.5f);
-  const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
-  return fmaf(x, pdf, cdf);
-}
-// The same function on a pair of elements with packed fp32 VALU (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two elements
-// per issue slot).  The GELU epilogue is VALU-bound (128 elements per lane after every tile, no MFMA beside it): per element
-// 6 single + exp + rcp issue slots become 3 packed + min + exp + rcp.  The range guard moves from x (v_med3) to x^2
-// (min(x^2, 64)): beyond |x| = 8 the exponent is then x * P(64) = -4.98 x, which saturates the sigmoid to 0 / 1 like the clamp
-// did (2^40 and up, or inf: rcp gives 0) - identical results inside the range, covered by test_gemm_gelu_bf16_range outside.
+// bf16 rounding of the activations it is summed with elsewhere.  fp32 mode: libm erff (parity).
+// Raw v_rcp_f32 / v_exp_f32 (1 ulp each): __frcp_rn expands to the full IEEE division sequence, ~10 instructions, and made
+// the GELU epilogue 40 k cycles.  Evaluated on a pair of elements with packed fp32 VALU (v_pk_mul_f32 / v_pk_fma_f32 /
+// v_pk_add_f32: two elements per issue slot).  The GELU epilogue is VALU-bound (128 elements per lane after every tile, no MFMA
+// beside it): per element 3 packed + min + exp + rcp issue slots.  The range guard sits on x^2
+// (min(x^2, 64)): beyond |x| = 8 the exponent is then x * P(64) = -4.98 x, which saturates the sigmoid to 0 / 1
+// (2^40 and up, or inf: rcp gives 0) - covered by test_gemm_gelu_bf16_range.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
   constexpr float A = -1.5950157686361435f * 1.4426950408889634f, B = -0.07401129203229191f * 1.4426950408889634f,
@@ -92,6 +65,26 @@ __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
   const f32x2 q = x * p;
   const f32x2 e = f32x2{__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)} + f32x2{1.0f, 1.0f};
   return x * f32x2{__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+}
+// d/dx of the SAME fitted function, gelu(x) ~ x s(x), s = sigmoid(p(x)), p = a x + b x^3 + c x^5:
+//   gelu'(x) ~ s (1 + x (1 - s) p'(x)),  p' = a + 3 b x^2 + 5 c x^4
+// |error| <= 1.1e-4 against Phi(x) + x phi(x) over the whole line (x^2 clamped at 64 as above: s -> 0 / 1 beyond), i.e. below the
+// bf16 rounding of the gradients it multiplies; 8 issue slots per element with the packed fp32 VALU against ~20 for the
+// erf-based form (the DGELU epilogue is VALU-bound like the GELU one).  bf16 training mode only; fp32 mode keeps libm.
+__device__ __forceinline__ f32x2 gelu_fast_grad2(f32x2 x) {
+  constexpr float L2E = 1.4426950408889634f;
+  constexpr float a = 1.5950157686361435f, b = 0.07401129203229191f, c = -0.000703033580348536f;
+  constexpr float A = -a * L2E, B = -b * L2E, Cc = -c * L2E;
+  f32x2 x2 = x * x;
+  x2.x = fminf(x2.x, 64.0f);
+  x2.y = fminf(x2.y, 64.0f);
+  const f32x2 q = x * __builtin_elementwise_fma(x2, __builtin_elementwise_fma(x2, f32x2{Cc, Cc}, f32x2{B, B}), f32x2{A, A});
+  const f32x2 e = f32x2{__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)} + f32x2{1.0f, 1.0f};
+  const f32x2 sg = f32x2{__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+  const f32x2 pp = __builtin_elementwise_fma(x2, __builtin_elementwise_fma(x2, f32x2{5.0f * c, 5.0f * c}, f32x2{3.0f * b, 3.0f * b}), f32x2{a, a});
+  const f32x2 u = x * pp;
+  const f32x2 w = __builtin_elementwise_fma(-sg, u, u);     // x p' (1 - s)
+  return __builtin_elementwise_fma(sg, w, sg);
 }
 template <typename T>
 __device__ __forceinline__ float4 gelu4(const float4& v) {
@@ -149,8 +142,10 @@ template <typename T>
 __device__ __forceinline__ float4 dgelu4(const float4& v, const float4& pre) {
   if constexpr (sizeof(T) == 4)
     return make_float4(v.x * gelu_erf_grad(pre.x), v.y * gelu_erf_grad(pre.y), v.z * gelu_erf_grad(pre.z), v.w * gelu_erf_grad(pre.w));
-  else
-    return make_float4(v.x * gelu_fast_grad(pre.x), v.y * gelu_fast_grad(pre.y), v.z * gelu_fast_grad(pre.z), v.w * gelu_fast_grad(pre.w));
+  else {
+    const f32x2 g0 = gelu_fast_grad2(f32x2{pre.x, pre.y}), g1 = gelu_fast_grad2(f32x2{pre.z, pre.w});
+    return make_float4(v.x * g0.x, v.y * g0.y, v.z * g1.x, v.w * g1.y);
+  }
 }
 
 // What an epilogue READS for 8 consecutive columns of one row (the residual, the running sum or the pre-activation).

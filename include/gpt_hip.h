@@ -43,7 +43,8 @@ int gpt_abi_version(void);
  * elements, K % 64 == 0 (bf16) or K % 32 == 0 (fp32), 16-byte aligned rows; N % 8 == 0, ldc % 4 == 0, C/aux/bias
  * 16-byte aligned (vector epilogue).  bias: fp32 or NULL.  GELU: fp32 mode uses libm erff (parity mode); bf16 mode uses
  * x * sigmoid(a x + b x^3 + c x^5) fitted to the exact erf GELU, |error| <= 2.6e-5 absolute (below the bf16 rounding of the
- * output; csrc/gemm_common.h gelu_fast2), and its derivative (GPT_EPI_DGELU) a 1.5e-7-accurate erf polynomial.
+ * output; csrc/gemm_common.h gelu_fast2), and GPT_EPI_DGELU multiplies by the derivative of that same fit, |error| <= 1.1e-4
+ * absolute against Phi(x) + x phi(x) (gelu_fast_grad2).
  * Replaces nn.Linear on the path: Gpt/models/transformer.py:38-40 (q,k,v), :50 (proj), :63-65 (mlp). */
 int gpt_gemm_nt(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                 void* C, int64_t ldc, void* aux, int64_t ldaux, int M, int N, int K, int epilogue,
