@@ -155,13 +155,25 @@ def main():
                          "`spread` reports median / min / max over all of them")
     args = ap.parse_args()
 
+    wd = float(os.environ.get("GPT_BENCH_WATCHDOG", "0"))      # seconds; a run that takes longer dumps every thread's stack and exits
+    if wd > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(wd, exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # GPT_BENCH_BACKEND=gloo GPT_BENCH_ONE_GPU=1: rehearsal of the N > 1 control flow of this file on a one-GPU machine (every
+    # rank on GPU 0, exchanges host-staged over gloo: g.pt_amd/dp.py); the numbers of such a run mean nothing
+    backend = os.environ.get("GPT_BENCH_BACKEND", "nccl")
+    if os.environ.get("GPT_BENCH_ONE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1 or os.environ.get("GPT_DP_REHEARSE") == "1":   # one-rank rehearsal of the RCCL calls: g.pt_amd/dp.py exchanging()
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from gpt_amd.trainstep import bench_train
@@ -302,10 +314,7 @@ def bench_sample(args, device, world, rank, cpu=True):
         local_rows = dp.gather_rows(runner.x, B * world)
     sync_all(world)
     elapsed = time.perf_counter() - t0
-    if dp.exchanging():
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = dp.max_over_ranks(elapsed, device)
     assert local_rows.shape == (B * world, D) and bool(torch.isfinite(runner.x).all())
     ms_per_step = elapsed * 1e3 / args.steps
     # the same region again (no gather): one number says nothing about its own spread

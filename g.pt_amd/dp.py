@@ -103,9 +103,23 @@ def gather_rows(local, n_rows):
     per = (n_rows + world - 1) // world
     pad = torch.zeros(per, *local.shape[1:], dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
+    if _host_staged(pad):                   # gloo rehearsal with several ranks on one GPU: its device all_gather does not return
+        h_pad = pad.cpu()
+        h_parts = [torch.empty_like(h_pad) for _ in range(world)]
+        dist.all_gather(h_parts, h_pad)
+        return torch.cat(h_parts, 0)[:n_rows].to(local.device)
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad)
     return torch.cat(parts, 0)[:n_rows]
+
+
+def max_over_ranks(value, device):
+    """MAX of a host scalar over the ranks (the timed region of bench.py: the slowest rank counts)."""
+    if not exchanging():
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def broadcast_parameters(module, src=0):

@@ -525,10 +525,7 @@ def bench_train(args, device, world, rank):
     mse = run(args.steps, args.warmup)
     sync_all(world)
     elapsed = time.perf_counter() - t0
-    if dp.exchanging():
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = dp.max_over_ranks(elapsed, device)
     loss = float(mse.mean().item())
     assert math.isfinite(loss), "training diverged"
     ms = elapsed * 1e3 / args.steps

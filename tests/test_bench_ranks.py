@@ -1,0 +1,34 @@
+"""bench.py's N > 1 control flow (rank-local inputs and Philox streams, barriers, the final gather of the samples, the MAX of the
+timed region over the ranks, the rank-0 line) rehearsed with two ranks on ONE GPU: every rank on device 0, exchanges host-staged
+over gloo (GPT_BENCH_BACKEND=gloo GPT_BENCH_ONE_GPU=1).  The driver runs the same file with one rank per GPU on RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["sample", "train"])
+def test_two_rank_bench_line(mode):
+    env = dict(os.environ, GPT_BENCH_BACKEND="gloo", GPT_BENCH_ONE_GPU="1", GPT_BENCH_WATCHDOG="200", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533" if mode == "sample" else "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--no-train", "--no-extra", "--no-roofline", "--no-cpu-baseline", "--repeats", "1"]
+    if mode == "train":
+        cmd += ["--mode", "train", "--batch", "32"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]                    # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0
+    if mode == "sample":
+        assert d["config"]["batch_per_gpu"] == 320 and d["scaling"] == "weak"
+        # value = the vectors of BOTH ranks over the slowest rank's time
+        assert abs(d["value"] - 2 * 320 / (d["ms_per_step"] * 1e-3 * 1000)) < 1e-6 * d["value"]
+    else:
+        assert d["config"]["global_batch"] == 64 and d["config"]["batch_per_gpu"] == 32
