@@ -155,7 +155,9 @@ def main():
                          "`spread` reports median / min / max over all of them")
     args = ap.parse_args()
 
-    wd = float(os.environ.get("GPT_BENCH_WATCHDOG", "0"))      # seconds; a run that takes longer dumps every thread's stack and exits
+    # seconds after which a run that is still going dumps every thread's stack and exits non-zero (a hung collective must leave a
+    # trace, not a silent process); 0 disables.  The default run takes two to three minutes.
+    wd = float(os.environ.get("GPT_BENCH_WATCHDOG", "900" if args.steps <= 2000 else "0"))
     if wd > 0:
         import faulthandler
         faulthandler.dump_traceback_later(wd, exit=True)
