@@ -85,10 +85,84 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+// RPW (two) rows per wave (d == NV * 256, no `add`): both rows' loads are in flight together and gamma / beta are read once for the
+// pair - at M = 8320 they were 12 KiB of L1 traffic per 6-KiB row.  Per row the arithmetic (and its order) is that of
+// layernorm_kernel: bit-identical results.
+template <int NV, int RPW, typename OutT>
+__global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, OutT* __restrict__ y,
+                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows, int d,
+                                                         float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row0 = RPW * (blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6));
+  if (row0 >= rows) return;
+  float4 v[RPW][NV];
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)min(row0 + rr, rows - 1) * d);   // past the end: the last row again
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[rr][i] = xr[lane + i * 64];
+  }
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+  float4 gm[NV], bt[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    gm[i] = g4[lane + i * 64];
+    bt[i] = b4[lane + i * 64];
+  }
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int row = row0 + rr;
+    if (row >= rows) break;                                 // wave-uniform
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[rr][i].x + v[rr][i].y) + (v[rr][i].z + v[rr][i].w);
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float a = v[rr][i].x - mean, b = v[rr][i].y - mean, c = v[rr][i].z - mean, e = v[rr][i].w - mean;
+      q += (a * a + b * b) + (c * c + e * e);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+    }
+    OutT* yr = y + (int64_t)row * d;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float4 t = v[rr][i], g = gm[i], b = bt[i];
+      float4 o;
+      o.x = (t.x - mean) * rstd * g.x + b.x;
+      o.y = (t.y - mean) * rstd * g.y + b.y;
+      o.z = (t.z - mean) * rstd * g.z + b.z;
+      o.w = (t.w - mean) * rstd * g.w + b.w;
+      if constexpr (sizeof(OutT) == 4) {
+        reinterpret_cast<float4*>(yr)[lane + i * 64] = o;
+      } else {
+        uint2 p;
+        p.x = pack_bf16x2(o.x, o.y);
+        p.y = pack_bf16x2(o.z, o.w);
+        reinterpret_cast<uint2*>(yr)[lane + i * 64] = p;
+      }
+    }
+  }
+}
+
 template <typename OutT>
 int launch(const float* x, const float* gamma, const float* beta, const float* add, int add_rows, void* y,
            float* mean, float* rstd, int rows, int d, float eps, hipStream_t s) {
   const dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(256);
+  static const bool pair = [] { const char* e = getenv("GPT_LN_PAIR"); return !e || atoi(e) != 0; }();   // 0: one row per wave (A/B)
+  if (pair && !add && rows >= 4096 && (d == 1536 || d == 2048)) {
+    constexpr int R = 2;                    // 3 rows per wave measure the same (5.766 against 5.770 ms per B = 320 sampling step), 4 worse (5.81)
+    const dim3 grid2((rows + R * ROWS_PER_BLOCK - 1) / (R * ROWS_PER_BLOCK));
+    if (d == 1536) hipLaunchKernelGGL((layernorm2_kernel<6, R, OutT>), grid2, block, 0, s, x, gamma, beta, (OutT*)y, mean, rstd, rows, d, eps);
+    else hipLaunchKernelGGL((layernorm2_kernel<8, R, OutT>), grid2, block, 0, s, x, gamma, beta, (OutT*)y, mean, rstd, rows, d, eps);
+    return gpt_launch_status("gpt_layernorm");
+  }
 #define LN_LAUNCH(NV)                                                                                          \
   hipLaunchKernelGGL((layernorm_kernel<NV, OutT>), grid, block, 0, s, x, gamma, beta, add, add_rows, (OutT*)y, \
                      mean, rstd, rows, d, eps)
