@@ -245,6 +245,38 @@ def test_layernorm(d, out_dtype):
     assert rel_err(y.float().cpu(), ref2) < tol
 
 
+@pytest.mark.parametrize("d", [1536, 2048])
+@pytest.mark.parametrize("out_dtype", ["fp32", "bf16"])
+def test_layernorm_many_rows(d, out_dtype):
+    """From 4096 rows up the widths of the two transformers take the two-rows-per-wave kernel (norm.hip layernorm2_kernel); an odd
+    row count leaves its last wave with one row.  Same arithmetic per row as the one-row kernel: the small-count call on the
+    first rows must give the same bits."""
+    g = torch.Generator().manual_seed(d + 1)
+    rows = 4099
+    x = torch.randn(rows, d, generator=g) * 2 - 0.25
+    w, b = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    ref = torch.nn.functional.layer_norm(x, (d,), w, b, 1e-5)
+    code = L.dtype_code(out_dtype)
+    td = L.torch_dtype(code)
+    y = torch.full((rows + 1, d), 7.0, dtype=td, device=DEV)                 # one guard row behind the output
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    L.check(L.lib().gpt_layernorm(L.ptr(xd), L.ptr(wd), L.ptr(bd), None, 0, L.ptr(y), code,
+                                  L.ptr(mean), L.ptr(rstd), rows, d, 1e-5, L.stream()), "ln")
+    assert rel_err(y[:rows].float().cpu(), ref) < (1e-5 if out_dtype == "fp32" else 1e-2)
+    assert bool((y[rows].float() == 7.0).all())
+    np.testing.assert_allclose(mean.cpu().numpy(), x.mean(1).numpy(), rtol=1e-5, atol=1e-6)
+    y1 = torch.empty(100, d, dtype=td, device=DEV)
+    L.check(L.lib().gpt_layernorm(L.ptr(xd), L.ptr(wd), L.ptr(bd), None, 0, L.ptr(y1), code, None, None, 100, d, 1e-5,
+                                  L.stream()), "ln")
+    assert torch.equal(y1, y[:100])
+    y2 = torch.empty(3, d, dtype=td, device=DEV)                             # the last rows, one-row kernel
+    tail = xd[rows - 3:].contiguous()
+    L.check(L.lib().gpt_layernorm(L.ptr(tail), L.ptr(wd), L.ptr(bd), None, 0, L.ptr(y2), code, None, None, 3, d, 1e-5,
+                                  L.stream()), "ln")
+    assert torch.equal(y2, y[rows - 3:rows])
+
+
 @pytest.mark.parametrize("dtype,tol", [("fp32", 1e-5), ("bf16", 1.5e-2)])
 @pytest.mark.parametrize("H,hd,T", [(2, 96, 26), (2, 128, 26), (16, 96, 26), (3, 32, 18), (2, 64, 32), (1, 96, 5),
                                     # T = 32 fills the per-wave LDS tile the output is staged through
