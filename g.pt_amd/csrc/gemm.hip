@@ -421,6 +421,91 @@ __global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(const float* __re
   }
 }
 
+// The same pass with WPR waves per row, one row per workgroup (each lane NV / WPR chunks of 16 bytes, the waves' sums meet in
+// LDS): at the small batches this pass runs on (M = 1664: 6.5 rows per CU) a wave per row leaves the CUs with too few waves to
+// hide the two memory latencies of a row.  The row sums are taken in another order than splitk_reduce_ln_kernel's: results agree
+// to rounding.
+template <int NV, int WPR, typename OutT>
+__global__ __launch_bounds__(WPR * 64) void splitk_reduce_ln2_kernel(const float* __restrict__ part, int nspan, const float* __restrict__ bias,
+                                                                     const float* resid, int64_t ldr, float* x, int64_t ldx,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                     OutT* __restrict__ y, float* __restrict__ mean_out,
+                                                                     float* __restrict__ rstd_out, int rows, float eps) {
+  static_assert(NV % WPR == 0, "the waves of a row take equal shares");
+  constexpr int d = NV * 256, H = NV / WPR;
+  __shared__ float red[2][WPR];                           // [sum | sumsq][wave]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x;
+  const int64_t slab = (int64_t)rows * d;
+  const int c0 = wave * H * 64 + lane;
+  const float4* pr = reinterpret_cast<const float4*>(part + (int64_t)row * d);
+  const float4* rr = reinterpret_cast<const float4*>(resid + (int64_t)row * ldr);
+  float4* xr = reinterpret_cast<float4*>(x + (int64_t)row * ldx);
+  float4 v[H], res[H];
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    v[i] = pr[c0 + i * 64];
+    res[i] = rr[c0 + i * 64];
+  }
+  for (int sp = 1; sp < nspan; ++sp) {
+    const float4* ps = reinterpret_cast<const float4*>(part + sp * slab + (int64_t)row * d);
+#pragma unroll
+    for (int i = 0; i < H; ++i) v[i] = add4(v[i], ps[c0 + i * 64]);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    const int c = c0 + i * 64;
+    if (bias) v[i] = add4(v[i], reinterpret_cast<const float4*>(bias)[c]);
+    v[i] = add4(res[i], v[i]);
+    xr[c] = v[i];
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  s = wave_sum(s);
+  if (lane == 0) red[0][wave] = s;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < WPR; ++w) tot += red[0][w];
+  const float mean = tot / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+    q += (a * a + b * b) + (c * c + e * e);
+  }
+  q = wave_sum(q);
+  if (lane == 0) red[1][wave] = q;
+  __syncthreads();
+  tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < WPR; ++w) tot += red[1][w];
+  const float rstd = 1.0f / sqrtf(tot / (float)d + eps);
+  if (threadIdx.x == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+  OutT* yr = y + (int64_t)row * d;
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    const int c = c0 + i * 64;
+    const float4 g = reinterpret_cast<const float4*>(gamma)[c], b = reinterpret_cast<const float4*>(beta)[c];
+    float4 o;
+    o.x = (v[i].x - mean) * rstd * g.x + b.x;
+    o.y = (v[i].y - mean) * rstd * g.y + b.y;
+    o.z = (v[i].z - mean) * rstd * g.z + b.z;
+    o.w = (v[i].w - mean) * rstd * g.w + b.w;
+    if constexpr (sizeof(OutT) == 4) {
+      reinterpret_cast<float4*>(yr)[c] = o;
+    } else {
+      uint2 pk;
+      pk.x = pack_bf16x2(o.x, o.y);
+      pk.y = pack_bf16x2(o.z, o.w);
+      reinterpret_cast<uint2*>(yr)[c] = pk;
+    }
+  }
+}
+
 int n_cus();
 
 // 128-row tiles: the three-stage 128 x 256 kernel (gemm128.hip); GPT_GEMM_128=0 falls back to the 256 x 256 kernel with half of
@@ -691,6 +776,16 @@ extern "C" int gpt_gemm_resadd_layernorm(int dtype, const void* A, int64_t lda, 
   const int rc = rt == 4 ? half_height_bf16(part, GPT_EPI_STORE_F32, s) : gemm256_bf16(part, GPT_EPI_STORE_F32, rt, s);
   if (rc != 0) return rc;
   const dim3 grid((M + 3) / 4), block(256);
+  // two waves per row at the small row counts (three measure the same, six worse: B = 64 sampling step 1.897 -> 1.876 / 1.871 / 1.894 ms)
+  static const bool splitrow = [] { const char* e = getenv("GPT_LN_SPLITROW"); return !e || atoi(e) != 0; }();   // 0: a wave per row (A/B)
+  if (splitrow && (nv == 6 || nv == 8) && M * 2 <= 32 * n_cus()) {
+#define RLN2(NV) hipLaunchKernelGGL((splitk_reduce_ln2_kernel<NV, 2, bf16_t>), dim3(M), dim3(128), 0, s, split_ws().ptr, sp, bias, resid, \
+                                    ldr, x, ldx, gamma, beta, (bf16_t*)y, mean, rstd, M, eps)
+    if (nv == 6) RLN2(6);
+    else RLN2(8);
+#undef RLN2
+    return gpt_launch_status("gpt_gemm_resadd_layernorm");
+  }
 #define RLN(NV) hipLaunchKernelGGL((splitk_reduce_ln_kernel<NV, bf16_t>), grid, block, 0, s, split_ws().ptr, sp, bias, resid, ldr, x, \
                                    ldx, gamma, beta, (bf16_t*)y, mean, rstd, M, eps)
   switch (nv) {
