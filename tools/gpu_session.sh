@@ -1,13 +1,7 @@
 set -o pipefail
 mkdir -p gpurun_out
-for rep in 1 2; do
-for c in 256 416 512; do
-  for b in 128 1024; do
-  GPT_LNB_BLOCKS=$c timeout -k 10 300 python bench.py --mode train --batch $b --steps 40 --warmup 10 --no-cpu-baseline --no-roofline > gpurun_out/red_t.json 2> gpurun_out/red_t.err || { tail -5 gpurun_out/red_t.err; exit 1; }
-  python -c "
-import json
-d=json.loads(open('gpurun_out/red_t.json').read().strip().splitlines()[-1])
-print('lnb blocks $c train B=$b ms',round(d['ms_per_step'],3))"
-  done
-done
-done
+timeout -k 10 1500 python -u -m pytest tests -x -q -m gpu --timeout 300 --timeout-method thread > gpurun_out/r2_gpu_all.log 2>&1; rc=$?; tail -3 gpurun_out/r2_gpu_all.log | cut -c1-300
+if grep -q "HSA_STATUS_ERROR\|Memory access fault" gpurun_out/r2_gpu_all.log; then echo FAULT; exit 1; fi
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1 || { tail -5 gpurun_out/smoke.log; exit 1; }
+tail -1 gpurun_out/smoke.log
