@@ -133,6 +133,22 @@ def cpu_baseline(case, seconds_target=20.0):
                       f"{B / dt:.1f} sample-steps/s"}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher in front: one fresh child process per GPU, as the reference starts its own
+    ranks (main.py:344-354, start_processes).  This parent has made no GPU call (nothing above touches the device before
+    main() parses its arguments): it starts `python -m torch.distributed.run` as a child with the same arguments, passes
+    the ranks' stdout (rank 0's one JSON line) and stderr through, and returns the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                       # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,6 +170,8 @@ def main():
                     help="the timed region of --steps steps is run this many times: `value` is the FIRST (the contract's region), "
                          "`spread` reports median / min / max over all of them")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     # seconds after which a run that is still going dumps every thread's stack and exits non-zero (a hung collective must leave a
     # trace, not a silent process); 0 disables.  The default run takes two to three minutes.

@@ -12,12 +12,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["sample", "train"])
-def test_two_rank_bench_line(mode):
+@pytest.mark.parametrize("mode,launcher", [("sample", "torchrun"), ("train", "torchrun"), ("sample", "bare")])
+def test_two_rank_bench_line(mode, launcher):
     env = dict(os.environ, GPT_BENCH_BACKEND="gloo", GPT_BENCH_ONE_GPU="1", GPT_BENCH_WATCHDOG="200", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533" if mode == "sample" else "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--no-train", "--no-extra", "--no-roofline", "--no-cpu-baseline", "--repeats", "1"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    # "bare": `python bench.py --gpus 2` with no launcher in front starts its own ranks (the reference's main.py:344-354 does)
+    front = ([sys.executable] if launcher == "bare" else
+             [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+              "--master-port", "29533" if mode == "sample" else "29534"])
+    cmd = front + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                   "--warmup", "1", "--no-train", "--no-extra", "--no-roofline", "--no-cpu-baseline", "--repeats", "1"]
     if mode == "train":
         cmd += ["--mode", "train", "--batch", "32"]
     res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
@@ -32,3 +37,29 @@ def test_two_rank_bench_line(mode):
         assert abs(d["value"] - 2 * 320 / (d["ms_per_step"] * 1e-3 * 1000)) < 1e-6 * d["value"]
     else:
         assert d["config"]["global_batch"] == 64 and d["config"]["batch_per_gpu"] == 32
+
+
+def test_bare_multi_gpu_invocation_spawns_ranks_before_any_gpu_call(monkeypatch):
+    """CPU: `python bench.py --gpus 2` without WORLD_SIZE must hand over to torch.distributed.run in a child process (and
+    return its exit code) without touching the device in the parent."""
+    import importlib
+    import subprocess as sp
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None, cwd=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    import torch
+    monkeypatch.setattr(sp, "call", fake_call)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *_: pytest.fail("the parent touched the GPU"))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]
