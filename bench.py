@@ -253,7 +253,7 @@ def guarded_train(args, device, world, rank, line, key, batch, scaling, limit_s=
         targs = argparse.Namespace(**vars(args))
         targs.steps, targs.warmup, targs.batch = 10, 3, batch
         res = bench_train(targs, device, world, rank)
-        keep = ("value", "unit", "ms_per_step", "steps", "warmup", "samples_per_s", "model_tflops_per_gpu", "final_loss")
+        keep = ("value", "unit", "ms_per_step", "steps", "warmup", "samples_per_s", "model_tflops_per_gpu", "final_loss", "first_step_check")
         out = {k: res[k] for k in keep}
         out.update(metric=res["metric"], scaling=scaling, global_batch=res["config"]["global_batch"],
                    batch_per_gpu=res["config"]["batch_per_gpu"], workload=res["config"]["workload"])

@@ -784,7 +784,8 @@ extern "C" int gpt_layernorm_bwd_colsum(const void* dy, int dy_dtype, const floa
   const bool dyb = dy_dtype == GPT_BF16, ob = gout_t_dtype == GPT_BF16;
 #define LNB(DY, OUT, NCH)                                                                                              \
   do {                                                                                                                  \
-    static bool attr_set = false; /* more than 64 KiB of dynamic LDS (d > 2048) must be granted once per kernel */      \
+    static GptPerDevice attr; /* more than 64 KiB of dynamic LDS (d > 2048) must be granted once per kernel and device */ \
+    bool& attr_set = attr.here();                                                                                       \
     if (!attr_set) {                                                                                                    \
       if (hipFuncSetAttribute((const void*)layernorm_bwd_kernel<DY, OUT, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               LNB_WAVES * NCH * 256 * (int)sizeof(float)) != hipSuccess) {                              \

@@ -24,6 +24,24 @@ void gpt_set_error(const char* fmt, ...);
     }                                   \
   } while (0)
 
+// Per-device "done once" state.  One process per GPU is the intended use, but nothing in the C ABI forbids a caller that drives
+// several devices: whatever is set up once (LDS grants of a kernel, event pools) is keyed by the CURRENT device.
+#define GPT_MAX_DEVICES 16
+static inline int gpt_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess) d = 0;
+  return d;
+}
+struct GptPerDevice {
+  bool done[GPT_MAX_DEVICES] = {};
+  bool& here() {
+    static thread_local bool never;   // device index out of range: set up again on every call (cheap, always right)
+    const int d = gpt_device();
+    if (d < 0 || d >= GPT_MAX_DEVICES) return never = false;
+    return done[d];
+  }
+};
+
 static inline int gpt_launch_status(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

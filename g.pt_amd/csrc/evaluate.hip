@@ -224,7 +224,8 @@ extern "C" int gpt_cnn_eval(const float* images, const int64_t* labels, const fl
   GPT_REQUIRE(images && labels && nets && partial && loss && err, "gpt_cnn_eval: null operand");
   GPT_REQUIRE(B > 0 && n_img > 0 && chunks > 0 && chunks <= n_img && chunks <= 65535, "gpt_cnn_eval: need B, n_img > 0 and 0 < chunks <= min(n_img, 65535)");
   GPT_REQUIRE(net_stride >= CNN_D && ((uintptr_t)images % 16) == 0, "gpt_cnn_eval: net_stride >= %d and 16-byte aligned images", CNN_D);
-  static bool attr_set = false;
+  static GptPerDevice attr;   // the LDS grant is per kernel AND per device (a process may drive several GPUs)
+  bool& attr_set = attr.here();
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)cnn_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CNN_LDS_BYTES) != hipSuccess) {
       gpt_set_error("gpt_cnn_eval: cannot reserve %d bytes of LDS", CNN_LDS_BYTES);

@@ -35,7 +35,7 @@
   } while (0)
 
 namespace gemmk {
-GemmProf g_prof;
+GemmProf g_prof_tab[GPT_MAX_DEVICES];
 int gemm256_bf16(const GemmArgs<bf16_t>& g, int epi, int rt, hipStream_t s);  // gemm256.hip; rt = 8 | 7 (256- / 224-row tiles)
 int gemm256_f32(const GemmArgs<float>& g, int epi, hipStream_t s);
 int gemm128_bf16(const GemmArgs<bf16_t>& g, int epi, hipStream_t s);          // gemm128.hip: 128 x 256 tiles, three stages
@@ -207,7 +207,8 @@ template <typename T, int EPI, int WM, int NSTAGE>
 int launch_shape(const GemmArgs<T>& g, hipStream_t s) {
   constexpr int BM = 64 * WM, BN = 128;
   constexpr int LDS = NSTAGE * (BM + BN) * ROWB;
-  static bool attr_set = false;
+  static GptPerDevice attr;   // the LDS grant is per kernel AND per device (a process may drive several GPUs)
+  bool& attr_set = attr.here();
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EPI, WM, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             LDS) != hipSuccess) {

@@ -159,7 +159,8 @@ __global__ __launch_bounds__(512, 2) void gemm128_kernel(GemmArgs<bf16_t> g) {
 
 template <int EPI>
 int launch128(const GemmArgs<bf16_t>& g, hipStream_t s) {
-  static bool attr_set = false;
+  static GptPerDevice attr;   // the LDS grant is per kernel AND per device (a process may drive several GPUs)
+  bool& attr_set = attr.here();
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)gemm128_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128_BYTES) != hipSuccess) {
       gpt_set_error("gpt_gemm_nt: cannot reserve %d bytes of LDS", LDS128_BYTES);

@@ -320,7 +320,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
 
 template <typename T, int EPI, int RT>
 int launch256(const GemmArgs<T>& g, hipStream_t s) {
-  static bool attr_set = false;
+  static GptPerDevice attr;   // the LDS grant is per kernel AND per device (a process may drive several GPUs)
+  bool& attr_set = attr.here();
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)gemm256_kernel<T, EPI, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
         hipSuccess) {

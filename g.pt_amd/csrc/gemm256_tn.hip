@@ -273,7 +273,8 @@ int pick_tn_spans(int tiles, int nk_all) {
 
 template <int EPI>
 int launch_tn(TnGroup& grp, hipStream_t s) {
-  static bool attr_set = false;
+  static GptPerDevice attr;   // the LDS grant is per kernel AND per device (a process may drive several GPUs)
+  bool& attr_set = attr.here();
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)gemm256_tn_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, TLDS_BYTES) !=
         hipSuccess) {

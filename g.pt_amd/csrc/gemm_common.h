@@ -302,6 +302,7 @@ struct GemmProf {
   double flops[CAP];
   bool made = false;
 };
-extern GemmProf g_prof;
+extern GemmProf g_prof_tab[GPT_MAX_DEVICES];   // one event pool per device (events belong to the device they were created on)
+#define g_prof (gemmk::g_prof_tab[(unsigned)gpt_device() % GPT_MAX_DEVICES])
 
 }  // namespace gemmk

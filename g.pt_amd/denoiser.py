@@ -201,6 +201,7 @@ class _Engine:
         self.struct = None          # parameter layout the pointer tables were built for
         self.gen = 0                # bumped whenever the packed operands were re-derived (or rewritten by the owner)
         self.managed = False
+        self.owner_sync = None      # managed engines: called before the operands are re-derived from the fp32 parameters
         self._versions = None
         self.keep_gen = 0           # bumped by every training forward (backward.py: one pending backward per engine)
         self.keep = []
@@ -232,6 +233,8 @@ class _Engine:
             self.struct = st
         elif self.managed and self._versions == tuple(p._version for p in m.parameters()):
             return                  # (a load_state_dict / optimizer.step behind the owner's back still shows in the counters)
+        if self.managed and self.owner_sync is not None:
+            self.owner_sync()       # sharded / overlapped owner: whole fp32 parameters before anything is derived from them
         self._repack(flat)
 
     def _repack(self, flat):

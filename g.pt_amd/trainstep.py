@@ -88,6 +88,7 @@ class TrainStep:
         # data-parallel optimizer sharding (fused step only; GPT_DP_SHARD=0 keeps every rank's full update)
         if shard is None:
             shard = os.environ.get("GPT_DP_SHARD", "1") != "0"
+        explicit = shard is True
         self.shard = bool(shard and fused and dp.exchanging())
         self.grad_payload = grad_payload or os.environ.get("GPT_DP_GRAD_PAYLOAD", "fp32")
         assert self.grad_payload in ("fp32", "bf16")
@@ -105,12 +106,26 @@ class TrainStep:
             bucket_layers = int(os.environ.get("GPT_DP_BUCKET_LAYERS", "2"))
         assert bucket_layers >= 1
         self.buckets = self._make_buckets(bucket_layers)
+        if self.shard and any((hi - lo) % (4 * self.world) for lo, hi, _, region in self.buckets if region == "S"):
+            # S buckets hold whole Linear weights (multiples of 64 elements): any world <= 16 that is a power of two divides them;
+            # 3, 6, 12 or more than 16 ranks (or an n_embd that is no multiple of 64) may not
+            assert not explicit, f"shard=True needs every S bucket to split evenly over {self.world} ranks (16-byte chunks)"
+            import warnings
+            warnings.warn(f"TrainStep: the weight buckets do not split evenly over {self.world} ranks; "
+                          "falling back to the replicated all-reduce step")
+            self.shard = False
+            self.exp_avg, self.exp_avg_sq = self.flat.like(), self.flat.like()
         if self.shard:
             self._init_shards()
         elif self.overlap_update:
             self.model.register_state_dict_pre_hook(lambda *a, **k: self.join())
             if self.ema is not None:
                 self.ema.register_state_dict_pre_hook(lambda *a, **k: self.join())
+                self.ema.register_forward_pre_hook(lambda *a, **k: self.join())
+        if fused:
+            # anything that makes the managed engine re-derive its operands from the fp32 parameters (a version bump behind the
+            # step's back) must first see whole, settled parameters: the other ranks' shards and the side-stream pass
+            self.eng.owner_sync = self.sync_params
         self.tmap = torch.tensor(diffusion._timestep_map(), device=self.device, dtype=torch.long)
         self.iteration = 0
 
@@ -154,7 +169,7 @@ class TrainStep:
         for lo, hi, _, region in self.buckets:
             if region != "S":
                 continue
-            assert (hi - lo) % (4 * w) == 0, "S buckets hold whole Linear weights (multiples of 64 elements): world <= 16"
+            assert (hi - lo) % (4 * w) == 0          # checked (with a fallback to the replicated step) in __init__
             c = (hi - lo) // w
             self.s_chunks.append((lo, hi, c, lo + r * c, g_off))
             g_off += c
@@ -173,6 +188,9 @@ class TrainStep:
         self.model.register_state_dict_pre_hook(lambda *a, **k: self.sync_params())
         if self.ema is not None:
             self.ema.register_state_dict_pre_hook(lambda *a, **k: self.sync_ema())
+            # a forward through the EMA copy mid-training (the reference's periodic EMA evaluation, main.py:303-308) goes through
+            # an unmanaged engine that repacks from flat_ema.params: the other ranks' shards must be there first
+            self.ema.register_forward_pre_hook(lambda *a, **k: self.sync_ema())
 
     def _launch_bucket(self, lo, hi, region):
         """Puts the gradient exchange of one finished bucket in flight."""
@@ -502,24 +520,51 @@ def bench_train(args, device, world, rank):
         order = torch.randperm(len(store), generator=torch.Generator().manual_seed(rank))
         rng = numpy.random.default_rng([1, rank])
 
+    def get_batch(i):
+        if store is not None:
+            b = store.get_batch(order[(i * B) % (len(store) - B):][:B].tolist(), rng)
+            return (b["parameters_0"], b["parameters_1"], b[metric + "_0"].to(device, non_blocking=True),
+                    b[metric + "_1"].to(device, non_blocking=True))
+        w_t, w_t1, l_t, l_t1 = batches[i % len(batches)]
+        if augment:     # one function-preserving permutation per pair, on the GPU (Gpt/data/augment.py:25-75)
+            seeds = range((i * world + rank) * B, (i * world + rank + 1) * B)
+            w_t, w_t1 = permute.random_permute_batch([w_t, w_t1], arch, seeds)
+        return w_t, w_t1, l_t, l_t1
+
     def run(n, first):
         last = None
         for i in range(first, first + n):
             ts.set_lr(lr_at(4e-4, 25000, 5, 0.0, i / iters_per_epoch))
             t, wts = sampler.sample(B, device)
-            if store is not None:
-                b = store.get_batch(order[(i * B) % (len(store) - B):][:B].tolist(), rng)
-                last = ts.step(b["parameters_0"], b["parameters_1"], b[metric + "_0"].to(device, non_blocking=True),
-                               b[metric + "_1"].to(device, non_blocking=True), t, weights=wts)
-                continue
-            w_t, w_t1, l_t, l_t1 = batches[i % len(batches)]
-            if augment:     # one function-preserving permutation per pair, on the GPU (Gpt/data/augment.py:25-75)
-                seeds = range((i * world + rank) * B, (i * world + rank + 1) * B)
-                w_t, w_t1 = permute.random_permute_batch([w_t, w_t1], arch, seeds)
+            w_t, w_t1, l_t, l_t1 = get_batch(i)
             last = ts.step(w_t, w_t1, l_t, l_t1, t, weights=wts)
         return last
 
-    run(args.warmup, 0)
+    # The first warm-up step is value-checked, whatever the batch size (the oracle comparisons of tests/test_hip_fullsize.py stop
+    # at B = 128): its per-row mse (training forward with kept activations at M = 26 B rows) against
+    # mean_flat((x_start - model(x_t, t))^2) (gaussian_diffusion.py:765-773) of its first <= 128 rows through the inference
+    # forward (other kernel instances at M <= 3328), same weights, t and noise.
+    first_check = None
+    n_warm = args.warmup
+    if args.warmup > 0:
+        ts.set_lr(lr_at(4e-4, 25000, 5, 0.0, 0.0))
+        t, wts = sampler.sample(B, device)
+        w_t, w_t1, l_t, l_t1 = get_batch(0)
+        noise = torch.empty_like(w_t1)
+        L.check(L.lib().gpt_randn(L.ptr(noise), noise.numel(), 0x5EED, rank, L.stream()), "gpt_randn")
+        n = min(B, 128)
+        with torch.no_grad():
+            x_t = diff.q_sample(w_t1[:n], t[:n], noise=noise[:n])
+            out = model(x_t, ts.tmap[t[:n]], l_t1[:n], loss_prev=l_t[:n], x_prev=w_t[:n])
+            target = w_t1[:n] if diff.model_mean_type == ModelMeanType.START_X else noise[:n]
+            want = (target - out).square().mean(dim=1)
+        got = ts.step(w_t, w_t1, l_t, l_t1, t, weights=wts, noise=noise)[:n]
+        rel = float(((got - want).abs() / want.abs().clamp_min(1e-12)).max())
+        bar = 2e-2 if args.dtype == "bf16" else 1e-3
+        assert rel < bar, f"first training step: per-row mse differs from the inference forward's by {rel:.3e} (bar {bar})"
+        first_check = {"rows": n, "mse_max_rel_err_vs_inference_forward": rel, "bar": bar, "loss": float(got.mean())}
+        n_warm -= 1
+    run(n_warm, 1)
     sync_all(world)
     t0 = time.perf_counter()
     mse = run(args.steps, args.warmup)
@@ -543,5 +588,5 @@ def bench_train(args, device, world, rank):
                                + ("; on-device permutation augmentation of every pair" if augment else ""),
                    "batch_per_gpu": B, "global_batch": B * world},
         "samples_per_s": B * world * 1e3 / ms, "model_tflops_per_gpu": flops / (ms * 1e-3) / 1e12,
-        "final_loss": loss,
+        "final_loss": loss, "first_step_check": first_check,
     }
