@@ -47,7 +47,11 @@ def flops_per_forward(case):
 
 def make_model(case, dtype, device, seed=0):
     torch.manual_seed(seed)
-    m = gpt_amd.Gpt(**gpt_kwargs(case))
+    if case == "cifar_big":          # 2.7 B parameters: drawn on the device (the host's generator needs half a minute for them)
+        with torch.device(device):
+            m = gpt_amd.Gpt(**gpt_kwargs(case))
+    else:
+        m = gpt_amd.Gpt(**gpt_kwargs(case))
     with torch.no_grad():                                    # the reference zero-inits these (identity model)
         m.decoder.pos_emb.normal_(0, 0.02)
         for p in m.decoder.output_parameter_projections:
@@ -133,6 +137,55 @@ def cpu_baseline(case, seconds_target=20.0):
                       f"{B / dt:.1f} sample-steps/s"}
 
 
+def cpu_baseline_train(case, iters=3):
+    """the reference's training iteration (main.py:32-81) restated on the oracle, on the host cores:
+    q_sample -> oracle forward -> mean_flat MSE -> autograd backward -> clip_grad_norm_ -> torch AdamW (two groups) -> EMA, at
+    B = 64, `iters` timed iterations after one untimed."""
+    from oracle import denoiser as od, diffusion as odf
+    c = CASES[case]
+    torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "64"))))
+    plan = od.Plan(c["parameter_sizes"], 128, 14, True, c["n_head"], c["n_embd"], c["n_layer"], c["chunk_size"],
+                   c["split_policy"], True)
+    sd = od.random_state_dict(plan, seed=0)
+    names = [k for k in sd if k != "scalar_embedder.frequencies"]
+    for k in names:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    decay = [k for k in names if k.endswith("weight") and ".ln" not in k and "ln_" not in k]
+    no_decay = [k for k in names if k not in set(decay)]
+    opt = torch.optim.AdamW([{"params": [sd[k] for k in decay], "weight_decay": 0.1},
+                             {"params": [sd[k] for k in no_decay], "weight_decay": 0.0}], lr=4e-4, betas=(0.9, 0.999))
+    ema = {k: sd[k].detach().clone() for k in names}
+    tb = odf.Tables(1000)
+    B = 64
+    g = torch.Generator().manual_seed(2)
+    w_t = torch.randn(B, plan.D, generator=g) * c["w_std"]
+    w_t1 = w_t + 0.1 * torch.randn(B, plan.D, generator=g)
+    l_t, l_t1 = (c["loss_lo"] + (c["loss_hi"] - c["loss_lo"]) * torch.rand(B, generator=g) for _ in range(2))
+
+    def iteration(i):
+        t = torch.randint(0, 1000, (B,), generator=g)
+        noise = torch.randn(B, plan.D, generator=g)
+        mse, _, _ = odf.training_mse(tb, lambda x, tm: od.forward(sd, plan, x, tm, l_t1, l_t, w_t), w_t1, t, noise)
+        loss = mse.mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([sd[k] for k in names], 0.75)
+        opt.step()
+        with torch.no_grad():
+            torch._foreach_mul_(list(ema.values()), 0.9999)
+            torch._foreach_add_(list(ema.values()), [sd[k].detach() for k in names], alpha=1 - 0.9999)
+        return float(loss.detach())
+
+    iteration(0)
+    t0 = time.perf_counter()
+    for i in range(iters):
+        loss = iteration(1 + i)
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": 1.0 / dt, "unit": "iters/s at B=64", "samples_per_s": B / dt, "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{iters} training iterations of the CPU oracle (PyTorch fp32 autograd + torch AdamW + EMA) at B={B}, {case} shapes, "
+                      f"{dt:.2f} s each; the GPU `train_weak` object runs B=128 per step", "final_loss": loss}
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher in front: one fresh child process per GPU, as the reference starts its own
     ranks (main.py:344-354, start_processes).  This parent has made no GPU call (nothing above touches the device before
@@ -203,12 +256,21 @@ def main():
         line = bench_sample(args, device, world, rank)
         if not args.no_extra and (args.case, args.dtype) == ("mnist", "bf16"):
             line["fp32"] = secondary_sample(args, device, world, rank, line, "fp32", "mnist", "fp32", args.batch or 320, 20, 3)
+            # configs[0] / [1] name 64 vectors: the small-batch leg of the same workload
+            line["b64"] = secondary_sample(args, device, world, rank, line, "b64", "mnist", "bf16", 64, 100, 10)
             line["cifar"] = secondary_sample(args, device, world, rank, line, "cifar", "cifar", "bf16", 1280, 20, 3)
         if not args.no_train:
             line["train"] = guarded_train(args, device, world, rank, line, "train", max(1, 1024 // world), "strong")
             # efficiency also at a fixed per-GPU batch: 128 pairs per GPU (the 8-GPU share of 1024) at every N
             line["train_weak"] = (dict(line["train"], scaling="weak") if 1024 // world == 128 else
                                   guarded_train(args, device, world, rank, line, "train_weak", 128, "weak"))
+            if not args.no_extra:
+                # configs[4]: CIFAR-10 shapes, scaled-up transformer (n_embd 3072, 24 heads, 24 layers: 2.7 B parameters), 550 / 8 = 68
+                # pairs per GPU, every pair permuted on the device inside the timed step
+                line["cifar_big"] = guarded_train(args, device, world, rank, line, "cifar_big", 68, "weak", limit_s=240.0,
+                                                  case="cifar_big", augment=True, steps=6, warmup=2)
+                if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                    line["cpu_baseline_train"] = guarded(lambda: cpu_baseline_train("mnist"), rank, line, "cpu_baseline_train", 400.0)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dp.exchanging():
@@ -243,7 +305,7 @@ def guarded(fn, rank, line, key, limit_s):
         timer.cancel()
 
 
-def guarded_train(args, device, world, rank, line, key, batch, scaling, limit_s=150.0):
+def guarded_train(args, device, world, rank, line, key, batch, scaling, limit_s=150.0, case=None, augment=None, steps=10, warmup=3):
     """BASELINE.json's second metric (train iters/sec, configs[3]) measured briefly after the headline, 10 timed steps:
     "train" at global batch 1024 = int(1024 / N) pairs per GPU as configs/train/mnist_loss.yaml runs it (strong scaling),
     "train_weak" at 128 pairs per GPU for every N."""
@@ -251,15 +313,23 @@ def guarded_train(args, device, world, rank, line, key, batch, scaling, limit_s=
 
     def run():
         targs = argparse.Namespace(**vars(args))
-        targs.steps, targs.warmup, targs.batch = 10, 3, batch
+        targs.steps, targs.warmup, targs.batch = steps, warmup, batch
+        if case is not None:
+            targs.case = case
+        if augment is not None:
+            targs.augment = augment
         res = bench_train(targs, device, world, rank)
-        keep = ("value", "unit", "ms_per_step", "steps", "warmup", "samples_per_s", "model_tflops_per_gpu", "final_loss", "first_step_check")
+        keep = ("value", "unit", "ms_per_step", "steps", "warmup", "samples_per_s", "model_tflops_per_gpu", "final_loss", "first_step_check",
+                "roofline")
         out = {k: res[k] for k in keep}
+        out["model_flops_frac_of_peak"] = res["model_tflops_per_gpu"] / PEAK[args.dtype]
         out.update(metric=res["metric"], scaling=scaling, global_batch=res["config"]["global_batch"],
                    batch_per_gpu=res["config"]["batch_per_gpu"], workload=res["config"]["workload"])
         return out
 
-    return guarded(run, rank, line, key, limit_s)
+    out = guarded(run, rank, line, key, limit_s)
+    torch.cuda.empty_cache()
+    return out
 
 
 def secondary_sample(args, device, world, rank, line, key, case, dtype, batch, steps, warmup, limit_s=150.0):

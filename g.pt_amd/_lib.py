@@ -100,6 +100,7 @@ _PROTOS = {
                                 C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i32, vp], i32),
     "gpt_perm_index_mlp": ([vp, vp, i32, i32, i32, i32, vp], i32),
     "gpt_perm_index_cnn": ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    "gpt_perm_index_chain": ([vp, vp, i32, i32, i32, C.POINTER(i32), vp], i32),
     "gpt_perm_gather": ([C.POINTER(vp), C.POINTER(vp), i32, vp, i32, i32, vp], i32),
     "gpt_denoiser_forward": ([C.POINTER(Model), C.POINTER(Workspace), vp, vp, vp, vp, i32, vp, vp, i32, vp], i32),
     "gpt_denoiser_backward": ([C.POINTER(Model), C.POINTER(Workspace), C.POINTER(Backward), vp, vp, vp, i32, vp], i32),

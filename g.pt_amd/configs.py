@@ -8,6 +8,11 @@ MNIST_NAMES = ["fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"]
 CIFAR_SIZES = [432, 4608, 320, 10]
 CIFAR_NAMES = ["conv1.weight", "conv2.weight", "fc.weight", "fc.bias"]
 
+# Cartpole policy (data_gen/train_rl.py:95-121 with data_gen/configs/rl/train/Cartpole.yaml:5: pi_hid_sizes [32, 32]; obs 4, act 1;
+# Gpt/tasks.py:75): state_dict order = log_std, then the actor's Linears
+CARTPOLE_SIZES = [1, 128, 32, 1024, 32, 32, 1]
+CARTPOLE_NAMES = ["log_std", "actor.0.weight", "actor.0.bias", "actor.2.weight", "actor.2.bias", "actor.4.weight", "actor.4.bias"]
+
 CASES = {
     # reduced-width models with the real token plans (26 tokens) and the real head dims (96 / 128)
     "mnist_small": dict(parameter_sizes=MNIST_SIZES, parameter_names=MNIST_NAMES, n_embd=192, n_head=2,
@@ -16,6 +21,9 @@ CASES = {
     "cifar_small": dict(parameter_sizes=CIFAR_SIZES, parameter_names=CIFAR_NAMES, n_embd=256, n_head=2,
                         n_layer=2, chunk_size=576, split_policy="chunk_within_layer", loss_lo=40.0, loss_hi=90.0,
                         loss_target=35.0, w_std=0.538),
+    "cartpole_small": dict(parameter_sizes=CARTPOLE_SIZES, parameter_names=CARTPOLE_NAMES, n_embd=256, n_head=2,
+                           n_layer=2, chunk_size=2048, split_policy="layer_by_layer", loss_lo=10.0, loss_hi=480.0,
+                           loss_target=500.0, w_std=0.538),
     # the pretrained configurations (configs/train/mnist_loss.yaml:34-47, cifar10_error.yaml:34-47)
     "mnist": dict(parameter_sizes=MNIST_SIZES, parameter_names=MNIST_NAMES, n_embd=1536, n_head=16,
                   n_layer=12, chunk_size=1000, split_policy="chunk_within_layer", loss_lo=0.3, loss_hi=2.4,
@@ -23,6 +31,11 @@ CASES = {
     "cifar": dict(parameter_sizes=CIFAR_SIZES, parameter_names=CIFAR_NAMES, n_embd=2048, n_head=16,
                   n_layer=12, chunk_size=576, split_policy="chunk_within_layer", loss_lo=40.0, loss_hi=90.0,
                   loss_target=35.0, w_std=0.538),
+    # the third shipped task (configs/train/cartpole.yaml:38-46): one token per parameter tensor, 18 tokens, 12 heads of 128;
+    # prompts are returns (Gpt/tasks.py:78-80: maximise, best_prompt 500)
+    "cartpole": dict(parameter_sizes=CARTPOLE_SIZES, parameter_names=CARTPOLE_NAMES, n_embd=1536, n_head=12,
+                     n_layer=12, chunk_size=2048, split_policy="layer_by_layer", loss_lo=10.0, loss_hi=480.0,
+                     loss_target=500.0, w_std=0.538),
     # BASELINE.json configs[4]: CIFAR shapes with a scaled-up transformer (the reference defines none)
     "cifar_big": dict(parameter_sizes=CIFAR_SIZES, parameter_names=CIFAR_NAMES, n_embd=3072, n_head=24,
                       n_layer=24, chunk_size=576, split_policy="chunk_within_layer", loss_lo=40.0, loss_hi=90.0,

@@ -1,7 +1,7 @@
 // On-device permutation augmentation: integer gather maps (bit-exact) and the gather itself.
 // Follows Gpt/data/augment.py:25-75 (random_permute_flat: one flat index built block by block in
 // state_dict order, the same index applied to both checkpoints of a pair) with the task functions
-// data_gen/train_mnist.py:28-50 (MLP) and data_gen/train_cifar10.py:27-47 (CNN).
+// data_gen/train_mnist.py:28-50 (MLP), data_gen/train_cifar10.py:27-47 (CNN) and data_gen/train_rl.py:51-74 (policy MLP chain).
 // HBM-bound integer/byte work: 8*D bytes written per index map; 4*D read + 4*D written (+8*D index) per
 // gathered vector.  Hidden-unit permutations are drawn on the host (torch.randperm on the reference's
 // generator) so the maps equal the reference's for the same seed.
@@ -43,6 +43,48 @@ __global__ __launch_bounds__(256) void index_cnn_kernel(const int32_t* __restric
       v = o1 + (int64_t)p2[o] * r2 + p1[rem / kk] * kk + rem % kk;
     } else if (i < o3) { const int j = i - o2; v = o2 + (j / C2) * C2 + p2[j % C2]; }
     else v = i;
+    out[i] = v;
+  }
+}
+
+// Policy MLP chain (data_gen/train_rl.py:51-74, random_permute_actor on VisActorCritic, train_rl.py:95-121): `prefix` unpermuted
+// leading scalars (log_std), then n_lin Linears (weight [dims[l+1], dims[l]] then bias [dims[l+1]]) in state_dict order.  Hidden
+// layer l < n_lin - 1 has its own permutation p_l (drawn input layer first): weight rows and bias follow p_l ('out'), weight
+// columns follow p_{l-1} ('in'; 'both' = [:, p_{l-1}][p_l] for the hidden layers); the output layer keeps its rows and bias.
+constexpr int MAX_CHAIN = 8;
+struct ChainArgs {
+  int dims[MAX_CHAIN + 1];
+  int n_lin, prefix, perm_len, D;
+};
+__global__ __launch_bounds__(256) void index_chain_kernel(const int32_t* __restrict__ perms, int64_t* __restrict__ index, ChainArgs c) {
+  const int s = blockIdx.y;
+  const int32_t* p = perms + (int64_t)s * c.perm_len;
+  int64_t* out = index + (int64_t)s * c.D;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < c.D; i += gridDim.x * blockDim.x) {
+    int64_t v = i;
+    int off = c.prefix, poff_in = 0, poff_out = 0;      // poff_out: where p_l starts; poff_in: where p_{l-1} starts
+    if (i >= off) {
+#pragma unroll 1
+      for (int l = 0; l < c.n_lin; ++l) {
+        const int n_in = c.dims[l], n_out = c.dims[l + 1];
+        const bool perm_out = l < c.n_lin - 1, perm_in = l > 0;
+        const int wsz = n_out * n_in;
+        if (i < off + wsz) {
+          const int j = i - off, r = j / n_in, col = j % n_in;
+          v = off + (int64_t)(perm_out ? p[poff_out + r] : r) * n_in + (perm_in ? p[poff_in + col] : col);
+          break;
+        }
+        off += wsz;
+        if (i < off + n_out) {
+          const int r = i - off;
+          v = off + (perm_out ? p[poff_out + r] : r);
+          break;
+        }
+        off += n_out;
+        poff_in = poff_out;
+        poff_out += n_out;
+      }
+    }
     out[i] = v;
   }
 }
@@ -112,6 +154,29 @@ extern "C" int gpt_perm_index_cnn(const int32_t* perms, int64_t* index, int n_sa
   const dim3 grid((D + 255) / 256 > 16 ? 16 : (D + 255) / 256, n_samples);
   hipLaunchKernelGGL(index_cnn_kernel, grid, dim3(256), 0, (hipStream_t)stream, perms, index, c_in, c1, c2, kk, n_out);
   return gpt_launch_status("gpt_perm_index_cnn");
+}
+
+extern "C" int gpt_perm_index_chain(const int32_t* perms, int64_t* index, int n_samples, int prefix, int n_dims, const int* host_dims,
+                                    void* stream) {
+  GPT_REQUIRE(perms && index && host_dims && n_samples > 0 && prefix >= 0, "gpt_perm_index_chain: bad arguments");
+  GPT_REQUIRE(n_dims >= 3 && n_dims <= MAX_CHAIN + 1, "gpt_perm_index_chain: 2 to %d Linears (3 to %d widths)", MAX_CHAIN, MAX_CHAIN + 1);
+  GPT_REQUIRE(n_samples <= 65535, "gpt_perm_index_chain: at most 65535 samples per call");
+  ChainArgs c;
+  c.n_lin = n_dims - 1;
+  c.prefix = prefix;
+  c.perm_len = 0;
+  int64_t D = prefix;
+  for (int l = 0; l < n_dims; ++l) {
+    GPT_REQUIRE(host_dims[l] > 0, "gpt_perm_index_chain: width %d is not positive", l);
+    c.dims[l] = host_dims[l];
+    if (l > 0) D += (int64_t)host_dims[l] * host_dims[l - 1] + host_dims[l];
+    if (l > 0 && l < n_dims - 1) c.perm_len += host_dims[l];
+  }
+  GPT_REQUIRE(D < (1ll << 31), "gpt_perm_index_chain: the flat vector has to stay below 2^31 elements");
+  c.D = (int)D;
+  const dim3 grid((c.D + 255) / 256 > 16 ? 16 : (c.D + 255) / 256, n_samples);
+  hipLaunchKernelGGL(index_chain_kernel, grid, dim3(256), 0, (hipStream_t)stream, perms, index, c);
+  return gpt_launch_status("gpt_perm_index_chain");
 }
 
 extern "C" int gpt_perm_gather(const float* const* host_src, float* const* host_dst, int n_nets, const int64_t* index,

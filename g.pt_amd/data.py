@@ -116,8 +116,10 @@ class _LmdbDb:
         return torch.frombuffer(bytearray(v), dtype=torch.float32)
 
 
-_ARCH = {"mnist_loss": P.MLP_ARCH, "mnist_error": P.MLP_ARCH, "cifar10_loss": P.CNN_ARCH, "cifar10_error": P.CNN_ARCH}
-_MINIMIZE = {"mnist_loss": True, "mnist_error": True, "cifar10_loss": True, "cifar10_error": True}   # Gpt/tasks.py:36-74
+_ARCH = {"mnist_loss": P.MLP_ARCH, "mnist_error": P.MLP_ARCH, "cifar10_loss": P.CNN_ARCH, "cifar10_error": P.CNN_ARCH,
+         "cartpole": P.ACTOR_ARCH}
+_MINIMIZE = {"mnist_loss": True, "mnist_error": True, "cifar10_loss": True, "cifar10_error": True,
+             "cartpole": False}                                                                     # Gpt/tasks.py:36-81
 
 
 class CheckpointStore:
@@ -127,7 +129,7 @@ class CheckpointStore:
                  single_run_debug=False, min_val=None, max_val=None, permute_augment=False, verify_done=False,
                  device="cuda", open_db=default_open_db, generator=None):
         if dataset_name not in _ARCH:
-            raise NotImplementedError(f"task {dataset_name!r}: only the MNIST MLP and CIFAR-10 ConvNet tasks are built")
+            raise NotImplementedError(f"task {dataset_name!r}: the MNIST MLP, CIFAR-10 ConvNet and Cartpole policy tasks are built")
         if normalizer_name not in ("openai", "none"):
             raise KeyError(normalizer_name)                                     # normalization.py:66-69
         lmdb_paths = sorted(glob(f"{dataset_dir}/*"))                           # dataset_lmdb.py:48-50

@@ -1,5 +1,5 @@
 """On-device permutation augmentation (reference: Gpt/data/augment.py:25-75 with
-data_gen/train_mnist.py:28-50 and data_gen/train_cifar10.py:27-47).
+data_gen/train_mnist.py:28-50, data_gen/train_cifar10.py:27-47 and data_gen/train_rl.py:51-74).
 
 The hidden-unit permutations are drawn on the host exactly as the reference draws them
 (torch.randperm on torch.Generator().manual_seed(seed), conv1 before conv2), so the flat index maps are
@@ -12,9 +12,14 @@ from . import _lib as L
 
 MLP_ARCH = dict(kind="mlp", n_in=784, hidden=10, n_out=10)            # data_gen/train_mnist.py:58-63
 CNN_ARCH = dict(kind="cnn", c_in=3, c1=16, c2=32, ksz=3, n_out=10)     # data_gen/train_cifar10.py:55-60
+# Cartpole policy: VisActorCritic("Cartpole", 4, 1), pi_hid_sizes [32, 32] (data_gen/train_rl.py:95-121, Gpt/tasks.py:75)
+ACTOR_ARCH = dict(kind="chain", prefix=1, dims=[4, 32, 32, 1])
 
 
 def arch_dim(arch):
+    if arch["kind"] == "chain":
+        d = arch["dims"]
+        return arch["prefix"] + sum(d[l + 1] * d[l] + d[l + 1] for l in range(len(d) - 1))
     if arch["kind"] == "mlp":
         return arch["hidden"] * arch["n_in"] + arch["hidden"] + arch["n_out"] * arch["hidden"] + arch["n_out"]
     kk = arch["ksz"] ** 2
@@ -24,7 +29,8 @@ def arch_dim(arch):
 def draw_permutations(arch, seeds):
     """int32 host tensor [n, perm_len]: per sample the hidden-unit permutations back to back.
     seeds: iterable of ints (or None entries: the global torch RNG, as augment.py:40-43)."""
-    widths = [arch["hidden"]] if arch["kind"] == "mlp" else [arch["c1"], arch["c2"]]
+    widths = ([arch["hidden"]] if arch["kind"] == "mlp" else arch["dims"][1:-1] if arch["kind"] == "chain"
+              else [arch["c1"], arch["c2"]])
     rows = []
     for seed in seeds:
         gen = torch.Generator().manual_seed(int(seed)) if seed is not None else None
@@ -37,7 +43,10 @@ def build_index(arch, perms, device):
     perms = perms.to(device=device, dtype=torch.int32).contiguous()
     n, D = perms.shape[0], arch_dim(arch)
     index = torch.empty(n, D, dtype=torch.int64, device=device)
-    if arch["kind"] == "mlp":
+    if arch["kind"] == "chain":
+        dims = (C.c_int * len(arch["dims"]))(*arch["dims"])
+        st = L.lib().gpt_perm_index_chain(L.ptr(perms), L.ptr(index), n, arch["prefix"], len(arch["dims"]), dims, L.stream())
+    elif arch["kind"] == "mlp":
         st = L.lib().gpt_perm_index_mlp(L.ptr(perms), L.ptr(index), n, arch["n_in"], arch["hidden"], arch["n_out"],
                                         L.stream())
     else:

@@ -575,6 +575,24 @@ def bench_train(args, device, world, rank):
     assert math.isfinite(loss), "training diverged"
     ms = elapsed * 1e3 / args.steps
     flops = 3 * flops_per_forward(case) * B
+    roofline = None
+    if not getattr(args, "no_roofline", False):
+        # the MFMA GEMM launches of the step (forward NT, dgrad NT incl. their K-span passes, weight-gradient TN), each bracketed
+        # by a pair of HIP events on its own stream in two extra, untimed steps: algorithmic 2 M N K FLOPs / summed kernel time
+        lib = L.lib()
+        sync_all(world)
+        L.check(lib.gpt_gemm_prof_enable(1), "prof")
+        run(2, args.warmup + args.steps)
+        torch.cuda.synchronize()
+        pms, pfl, pnl = C.c_double(), C.c_double(), C.c_int()
+        L.check(lib.gpt_gemm_prof_collect(C.byref(pms), C.byref(pfl), C.byref(pnl)), "prof")
+        L.check(lib.gpt_gemm_prof_enable(0), "prof")
+        if pnl.value and pms.value > 0:
+            ach = pfl.value / (pms.value * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "achieved": ach, "peak": PEAK[args.dtype], "unit": "TFLOP/s", "frac": ach / PEAK[args.dtype],
+                        "traffic": None, "kernel": "all MFMA GEMM launches of the training step (gemm256 / gemm128 / gemm_nt forward and "
+                        "dgrad, gemm256_tn weight gradients), HIP events on the launch stream",
+                        "launches_per_step": pnl.value / 2, "gemm_ms_per_step": pms.value / 2, "flops_per_step": pfl.value / 2}
     return {
         "metric": "train iters/sec (DDP)", "value": 1e3 / ms, "unit": "iters/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -588,5 +606,5 @@ def bench_train(args, device, world, rank):
                                + ("; on-device permutation augmentation of every pair" if augment else ""),
                    "batch_per_gpu": B, "global_batch": B * world},
         "samples_per_s": B * world * 1e3 / ms, "model_tflops_per_gpu": flops / (ms * 1e-3) / 1e12,
-        "final_loss": loss, "first_step_check": first_check,
+        "final_loss": loss, "first_step_check": first_check, "roofline": roofline,
     }

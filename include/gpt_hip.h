@@ -253,6 +253,12 @@ int gpt_perm_index_mlp(const int32_t* perms, int64_t* index, int n_samples, int 
                        void* stream);
 int gpt_perm_index_cnn(const int32_t* perms, int64_t* index, int n_samples, int c_in, int c1, int c2, int ksz,
                        int n_out, void* stream);
+/* The Cartpole policy (data_gen/train_rl.py:51-74 random_permute_actor on VisActorCritic, train_rl.py:95-121; Gpt/tasks.py:73-81):
+ * `prefix` leading scalars kept in place (log_std), then n_dims - 1 Linears of widths host_dims[0..n_dims) (weight [out, in]
+ * then bias, state_dict order).  perms: per sample the permutations of the HIDDEN widths host_dims[1..n_dims-1) back to back,
+ * in the order the reference draws them (input layer first).  index: int64 [n_samples, D]. */
+int gpt_perm_index_chain(const int32_t* perms, int64_t* index, int n_samples, int prefix, int n_dims, const int* host_dims,
+                         void* stream);
 /* dst[s, i] = src[s, index[s, i]] for n_nets tensors sharing the index (both checkpoints of a pair). */
 int gpt_perm_gather(const float* const* host_src, float* const* host_dst, int n_nets, const int64_t* index,
                     int n_samples, int D, void* stream);

@@ -3,8 +3,8 @@ oracle/__init__.py).  Integer work: parity bar is BIT-EXACT.
 
 Follows Gpt/data/augment.py:25-75 (random_permute_flat: one flat gather index, built block by
 block in state_dict order) with the task permutation functions
-data_gen/train_mnist.py:28-50 (random_permute_mlp) and data_gen/train_cifar10.py:27-47
-(random_permute_cnn).  Hidden-unit permutations come from torch's CPU ``randperm`` on a
+data_gen/train_mnist.py:28-50 (random_permute_mlp), data_gen/train_cifar10.py:27-47
+(random_permute_cnn) and data_gen/train_rl.py:51-74 (random_permute_actor).  Hidden-unit permutations come from torch's CPU ``randperm`` on a
 ``torch.Generator().manual_seed(seed)`` (augment.py:40-43), so the oracle draws them the same way.
 """
 import numpy as np
@@ -61,6 +61,29 @@ def cnn_index(p1, p2, c_in=3, k=3, n_out=10):
     off += n_out * C2
     fcb = off + np.arange(n_out)
     return np.concatenate([conv1, conv2, fc, fcb]).astype(np.int64)
+
+
+def draw_actor(seed, hidden=(32, 32)):
+    """One permutation per hidden layer of the policy, drawn input layer first (train_rl.py:64-73)."""
+    gen = torch.Generator().manual_seed(seed) if seed is not None else None
+    return tuple(_randperm(h, gen) for h in hidden)
+
+
+def actor_index(perms, obs=4, act=1):
+    """VisActorCritic (train_rl.py:95-121): log_std (act) registered unchanged, then the actor's Linears in state_dict order:
+    input layer weight + bias 'out' (rows permuted), hidden layers weight 'both' = [:, p_prev][p_new] and bias 'out',
+    output layer weight 'in' (columns permuted by the last hidden permutation), bias registered (train_rl.py:61-73)."""
+    dims = [obs] + [len(p) for p in perms] + [act]
+    parts, off = [np.arange(act)], act
+    for l in range(len(dims) - 1):
+        n_in, n_out = dims[l], dims[l + 1]
+        pin = perms[l - 1] if l > 0 else np.arange(n_in)
+        pout = perms[l] if l < len(perms) else np.arange(n_out)
+        parts.append((off + pout[:, None] * n_in + pin[None, :]).reshape(-1))
+        off += n_out * n_in
+        parts.append(off + pout)
+        off += n_out
+    return np.concatenate(parts).astype(np.int64)
 
 
 def permute(nets, index):

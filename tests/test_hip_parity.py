@@ -307,7 +307,7 @@ def test_scalar_tokens_golden(golden):
 
 
 # ------------------------------------------------------------------------------------------ denoiser
-@pytest.mark.parametrize("case", ["mnist_small", "cifar_small"])
+@pytest.mark.parametrize("case", ["mnist_small", "cifar_small", "cartpole_small"])
 def test_forward_golden_fp32(golden, case):
     g = golden(f"g3_forward_{case}")
     m, plan, sd = build(case, "fp32")
@@ -397,7 +397,7 @@ def test_forward_edge_batches_and_argument_forms(B):
         m(x[:, :-1].to(DEV), t.to(DEV), lt.to(DEV), loss_prev=lp.to(DEV), x_prev=xp[:, :-1].to(DEV))
 
 
-@pytest.mark.parametrize("case", ["mnist_small", "cifar_small"])
+@pytest.mark.parametrize("case", ["mnist_small", "cifar_small", "cartpole_small"])
 def test_forward_oracle_bf16(case):
     m, plan, sd = build(case, "bf16", seed=3)
     cpu = make_inputs(case, B=7, seed=5)
@@ -648,6 +648,52 @@ def test_permutation_maps_bit_exact(golden):
         pa, pb = P.random_permute_batch([a.to(DEV), b.to(DEV)], arch, range(16))
         ia = torch.from_numpy(index)
         assert torch.equal(pa.cpu(), torch.gather(a, 1, ia)) and torch.equal(pb.cpu(), torch.gather(b, 1, ia))
+
+
+def test_actor_permutation_maps_bit_exact(golden):
+    """The third shipped task (Cartpole policy, data_gen/train_rl.py:51-74): int64 maps of gpt_perm_index_chain against the
+    reference's (fixture g15, 16 seeds) and the oracle's, and the gather of a pair through them."""
+    g = golden("g15_actor_permute")
+    P = gpt_amd.permute
+    arch = P.ACTOR_ARCH
+    assert P.arch_dim(arch) == 1250
+    perms = P.draw_permutations(arch, range(16))
+    index = P.build_index(arch, perms, DEV).cpu().numpy()
+    assert index.dtype == np.int64 and np.array_equal(index, g["actor"].astype(np.int64))
+    assert np.array_equal(index[7], op.actor_index(op.draw_actor(7)))
+    gen = torch.Generator().manual_seed(2)
+    a, b = torch.randn(16, 1250, generator=gen), torch.randn(16, 1250, generator=gen)
+    pa, pb = P.random_permute_batch([a.to(DEV), b.to(DEV)], arch, range(16))
+    ia = torch.from_numpy(index)
+    assert torch.equal(pa.cpu(), torch.gather(a, 1, ia)) and torch.equal(pb.cpu(), torch.gather(b, 1, ia))
+    # a deeper chain with other widths (three hidden layers, two leading scalars) against the oracle's construction
+    arch2 = dict(kind="chain", prefix=2, dims=[5, 7, 16, 3, 2])
+    perms2 = P.draw_permutations(arch2, [11, 12])
+    idx2 = P.build_index(arch2, perms2, DEV).cpu().numpy()
+    for row, seed in zip(idx2, (11, 12)):
+        want = op.actor_index(op.draw_actor(seed, (7, 16, 3)), obs=5, act=2)
+        assert np.array_equal(row, want) and sorted(row.tolist()) == list(range(P.arch_dim(arch2)))
+    # rejected before launch: a chain with one Linear, too many widths
+    import ctypes as C
+    lib = L.lib()
+    assert lib.gpt_perm_index_chain(L.ptr(perms.to(DEV)), L.ptr(torch.empty(4, dtype=torch.long, device=DEV)), 1, 0, 2, (C.c_int * 2)(4, 1), L.stream()) != 0
+    assert lib.gpt_perm_index_chain(L.ptr(perms.to(DEV)), L.ptr(torch.empty(4, dtype=torch.long, device=DEV)), 1, 0, 10, (C.c_int * 10)(*[2] * 10), L.stream()) != 0
+
+
+@pytest.mark.parametrize("dtype,bar", [("fp32", 1e-3), ("bf16", 3e-2)])
+def test_cartpole_full_size_forward_vs_oracle(dtype, bar):
+    """configs/train/cartpole.yaml:38-46 at its real shapes: layer_by_layer tokens (18 of them, widths 1 ... 1024), n_embd 1536,
+    12 heads of 128, 12 layers; prompts are returns (hundreds), B = 8 (the reference's vis batch, cartpole.yaml:22-24)."""
+    case = "cartpole"
+    m, plan, sd = build(case, dtype, seed=15)
+    assert plan.T == 18
+    cpu = make_inputs(case, B=8, seed=41)
+    x, t, lt, lp, xp = (v.to(DEV) for v in cpu)
+    with torch.no_grad():
+        out = m(x, t, lt, loss_prev=lp, x_prev=xp).cpu()
+        ref = od.forward(sd, plan, *cpu)
+    scale = float((ref - cpu[4]).abs().max())
+    assert float((out - ref).abs().max()) / scale < bar
 
 
 def test_batched_mlp_eval_golden_and_oracle(golden):

@@ -40,7 +40,7 @@ def test_g2_freq(golden):
     assert np.array_equal(od.freq_embed(torch.from_numpy(g["l32"]).view(-1, 1), f).numpy(), g["l32_col_emb"])
 
 
-@pytest.mark.parametrize("case", ["mnist_small", "cifar_small"])
+@pytest.mark.parametrize("case", ["mnist_small", "cifar_small", "cartpole_small"])
 def test_g3_forward(golden, case):
     g = golden(f"g3_forward_{case}")
     plan = plan_of(case)
@@ -141,6 +141,17 @@ def test_g8_permute(golden):
         assert np.array_equal(op.mlp_index(*op.draw_mlp(seed)), g["mlp"][seed].astype(np.int64))
         assert np.array_equal(op.cnn_index(*op.draw_cnn(seed)), g["cnn"][seed].astype(np.int64))
         assert sorted(op.mlp_index(*op.draw_mlp(seed)).tolist()) == list(range(7960))
+
+
+def test_g15_actor_permute(golden):
+    """The Cartpole policy's maps (data_gen/train_rl.py:51-74 run on the reference's VisActorCritic layout, 16 seeds)."""
+    g = golden("g15_actor_permute")
+    hid = tuple(int(h) for h in g["hidden"])
+    assert hid == (32, 32) and g["sizes"].tolist() == [1, 128, 32, 1024, 32, 32, 1]
+    for seed in range(16):
+        idx = op.actor_index(op.draw_actor(seed, hid))
+        assert np.array_equal(idx, g["actor"][seed].astype(np.int64))
+        assert sorted(idx.tolist()) == list(range(1250))
 
 
 def test_g10_mlp_eval(golden):

@@ -2,11 +2,18 @@ set -o pipefail
 mkdir -p gpurun_out
 L=gpurun_out/r3_new.log
 timeout -k 10 900 python -u -m pytest -x -q -m gpu --timeout 400 --timeout-method thread -s \
-  "tests/test_hip_training.py::test_fused_step_matches_torch_optimizer_tight_bar_in_the_deterministic_configuration" \
-  "tests/test_hip_training.py::test_one_rank_rccl_rehearsal_matches_single_process" \
-  "tests/test_hip_fullsize.py::test_large_batch_gradients_equal_mean_of_b128_slices" > $L 2>&1; rc=$?
+  "tests/test_hip_parity.py::test_actor_permutation_maps_bit_exact" "tests/test_hip_parity.py::test_cartpole_full_size_forward_vs_oracle" \
+  "tests/test_hip_parity.py::test_forward_golden_fp32" "tests/test_hip_parity.py::test_forward_oracle_bf16" \
+  "tests/test_hip_parity.py::test_permutation_maps_bit_exact" > $L 2>&1; rc=$?
 grep -E "^\[|passed|failed|Error|error" $L | grep -v Gloo | cut -c1-400 | tail -30
 if grep -q "HSA_STATUS_ERROR\|Memory access fault" $L; then echo FAULT; exit 1; fi
 [ $rc -eq 0 ] || exit $rc
-timeout -k 10 500 python bench.py > gpurun_out/r3_bench0.json 2> gpurun_out/r3_bench0.err || { tail -20 gpurun_out/r3_bench0.err; exit 1; }
-cat gpurun_out/r3_bench0.json | cut -c1-3000
+/usr/bin/time -v timeout -k 10 700 python bench.py > gpurun_out/r3_bench1.json 2> gpurun_out/r3_bench1.err || { tail -20 gpurun_out/r3_bench1.err; exit 1; }
+grep -E "Elapsed|Maximum resident" gpurun_out/r3_bench1.err
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/r3_bench1.json'))
+print('headline', d['value'], d['ms_per_step'], d['roofline']['frac'])
+for k in ('fp32','b64','cifar','train','train_weak','cifar_big','cpu_baseline_train','cpu_baseline'):
+    print(k, json.dumps(d.get(k))[:700])
+PY

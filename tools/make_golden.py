@@ -264,6 +264,71 @@ def g8_permute():
     save("g8_permute", **out)
 
 
+# ------------------------------------------------------------------ G15: Cartpole policy permutation maps (the third shipped task)
+def _reference_defs(path, names):
+    """Compiles the named top-level definitions of one reference file, read as text at generation time, WITHOUT importing the
+    module: data_gen/train_rl.py imports gym / hydra / omegaconf / isaacgym at module level, none of which exists here, and
+    its permutation code uses none of them.  Nothing of the file is kept in this repository."""
+    import ast
+    tree = ast.parse(open(path).read(), filename=path)
+    body = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in names]
+    assert {n.name for n in body} == set(names)
+    from Gpt.data.augment import permute_in, permute_out, permute_in_out
+    import torch.nn as nn
+    ns = {"torch": torch, "nn": nn, "np": np, "permute_in": permute_in, "permute_out": permute_out,
+          "permute_in_out": permute_in_out, "_TASKS": {"Cartpole": None}}
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def reference_actor():
+    """The reference's VisActorCritic('Cartpole', 4, 1) (Gpt/tasks.py:75) and random_permute_actor.  The class's __init__ reads its
+    layer widths with OmegaConf (absent here): the instance is made with __new__ and given the attributes __init__ would
+    (train_rl.py:108-121: actor = Linear / SELU chain over pi_hid_sizes, then log_std), the widths read from the reference's
+    own data_gen/configs/rl/train/Cartpole.yaml."""
+    import yaml
+    import torch.nn as nn
+    ns = _reference_defs("/root/reference/data_gen/train_rl.py", ["random_permute_actor", "VisActorCritic"])
+    with open("/root/reference/data_gen/configs/rl/train/Cartpole.yaml") as f:
+        hid = yaml.safe_load(f)["policy"]["pi_hid_sizes"]
+    cls = ns["VisActorCritic"]
+    net = cls.__new__(cls)
+    nn.Module.__init__(net)
+    dims = [4] + list(hid) + [1]
+    layers = []
+    for l in range(len(dims) - 1):
+        layers.append(nn.Linear(dims[l], dims[l + 1]))
+        if l < len(dims) - 2:
+            layers.append(nn.SELU())
+    net.actor = nn.Sequential(*layers)
+    net.log_std = nn.Parameter(torch.zeros(1))
+    return net, ns["random_permute_actor"], hid
+
+
+def g15_actor_permute():
+    torch.manual_seed(15)
+    net, fn, hid = reference_actor()
+    keys = list(net.state_dict().keys())
+    sizes = [v.numel() for v in net.state_dict().values()]
+    from gpt_amd.configs import CARTPOLE_NAMES, CARTPOLE_SIZES
+    assert keys == CARTPOLE_NAMES and sizes == CARTPOLE_SIZES, (keys, sizes)
+    D = sum(sizes)
+    ident = torch.arange(D)
+    maps = np.stack([random_permute_flat(ident, net, seed, fn).numpy() for seed in range(16)]).astype(np.int32)
+    # function preservation (sanity): the permuted flat vector, loaded back, computes the same policy mean
+    flat = torch.cat([v.flatten() for v in net.state_dict().values()])
+    obs = torch.randn(5, 4)
+    want = net.actor(obs)
+    perm = flat[torch.from_numpy(maps[3]).long()]
+    off, sd = 0, {}
+    for k, v in net.state_dict().items():
+        sd[k] = perm[off:off + v.numel()].view(v.shape)
+        off += v.numel()
+    net.load_state_dict(sd)
+    assert torch.allclose(net.actor(obs), want, atol=1e-6)
+    save("g15_actor_permute", actor=maps, hidden=np.array(hid), sizes=np.array(sizes))
+
+
 # ------------------------------------------------------------------ G9: one optimisation step
 def g9_trainstep(case):
     from copy import deepcopy
@@ -429,6 +494,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g12":          # only the ConvNet fixture (added after G1-G11)
         g12_cnn_eval()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "cartpole":     # the third shipped task (added in round 3)
+        g3_forward("cartpole_small")
+        g15_actor_permute()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g11":          # only the DDIM fixtures (added after G1-G10)
         g11_ddim("mnist_small", "ddim25", "ddim25_eta0", 0.0)
         g11_ddim("mnist_small", "50", "r50_eta05", 0.5)
@@ -436,7 +505,7 @@ if __name__ == "__main__":
         sys.exit(0)
     g1_splits()
     g2_freq()
-    for case in ("mnist_small", "cifar_small"):
+    for case in ("mnist_small", "cifar_small", "cartpole_small"):
         g3_forward(case)
     g4_block()
     g5_tables()
@@ -456,3 +525,4 @@ if __name__ == "__main__":
     g12_cnn_eval()
     g13_pairs()
     g14_diffusion_misc()
+    g15_actor_permute()
