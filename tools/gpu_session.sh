@@ -8,8 +8,8 @@ timeout -k 10 900 python -u -m pytest -x -q -m gpu --timeout 400 --timeout-metho
 grep -E "^\[|passed|failed|Error|error" $L | grep -v Gloo | cut -c1-400 | tail -30
 if grep -q "HSA_STATUS_ERROR\|Memory access fault" $L; then echo FAULT; exit 1; fi
 [ $rc -eq 0 ] || exit $rc
-/usr/bin/time -v timeout -k 10 700 python bench.py > gpurun_out/r3_bench1.json 2> gpurun_out/r3_bench1.err || { tail -20 gpurun_out/r3_bench1.err; exit 1; }
-grep -E "Elapsed|Maximum resident" gpurun_out/r3_bench1.err
+S0=$(date +%s); timeout -k 10 700 python bench.py > gpurun_out/r3_bench1.json 2> gpurun_out/r3_bench1.err || { tail -20 gpurun_out/r3_bench1.err; exit 1; }
+echo "bench wall: $(( $(date +%s) - S0 )) s"
 python - <<'PY'
 import json
 d=json.load(open('gpurun_out/r3_bench1.json'))
