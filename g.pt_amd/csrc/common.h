@@ -100,6 +100,11 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 int gpt_tn_grouped_sumsq(int n, const void* const* P, const int64_t* ldp, const void* const* Q, const int64_t* ldq, float* const* C,
                          const int64_t* ldc, const int* I, const int* J, int R, int accumulate, float* sumsq, void* stream);
 
+// gpt_randn (stream (seed, sid) over a [B, D] buffer) + gpt_posterior_step with every row at timestep t, in one kernel (the DDPM
+// sampling loop's step; bit-identical to the two calls)
+int gpt_posterior_step_philox(const float* model_out, const float* x_t, int64_t t, const float* coef, int predict_xstart, int use_clamp,
+                              float lo, float hi, uint64_t seed, uint64_t sid, float* x_out, int B, int D, void* stream);
+
 // gpt_small_gemm_batched with one more (internal) argument: bf16_mma != 0 rounds both operands to bf16 and multiplies them on the
 // bf16 matrix pipe (the denoiser backward in bf16 compute mode); 0 = the exact-fp32 pipe
 int gpt_small_gemm_batched_mode(int n_problems, int a_dtype, const void* const* host_A, int64_t a_sm, int64_t a_sk, int b_dtype,

@@ -64,6 +64,34 @@ __device__ __forceinline__ float post_one(float mo, float xt, float nz, const Po
   return mean + p.sigma * nz;
 }
 
+// Philox4x32-10 -> four N(0,1) by Box-Muller: block q of stream (seed, sid) = elements [4 q, 4 q + 4) of gpt_randn's output
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox_normals4(int64_t q, uint64_t seed, uint64_t sid, float (&z)[4]) {
+  uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)sid, (uint32_t)(sid >> 32)};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
+    const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(6.28318530717958647692f * u2, &sn, &cs);
+    z[2 * h] = rad * cs;
+    z[2 * h + 1] = rad * sn;
+  }
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict__ mo, const float* __restrict__ xt,
                                                         const float* __restrict__ noise, const int64_t* __restrict__ t,
@@ -93,6 +121,35 @@ __global__ __launch_bounds__(256) void posterior_kernel(const float* __restrict_
     for (int e = 0; e < V; ++e) r.v[e] = post_one(m.v[e], x.v[e], n.v[e], p, predict_xstart, use_clamp, lo, hi, &z.v[e]);
     vstore<V>(xout + o, r);
     if (x0out) vstore<V>(x0out + o, z);
+  }
+}
+
+// The sampling loop's step: every row is at the same timestep and the noise is drawn in the kernel - the Philox block of flat
+// element index e is e >> 2 of stream (seed, sid), i.e. exactly what gpt_randn would have written to a [B, D] buffer, so the
+// result equals gpt_randn + gpt_posterior_step bit for bit, without the 2 x 4 B D bytes of the noise round trip, the randn
+// launch and the timestep fill.  V = 2 / 1 (D % 4 != 0) recompute the block for every V elements.
+template <int V>
+__global__ __launch_bounds__(256) void posterior_philox_kernel(const float* __restrict__ mo, const float* __restrict__ xt, int64_t tb,
+                                                               const float* __restrict__ coef, int predict_xstart, int use_clamp,
+                                                               float lo, float hi, uint64_t seed, uint64_t sid,
+                                                               float* __restrict__ xout, int B, int DV) {
+  const int b = blockIdx.y;
+  PostScal p;
+  p.c1 = coef[tb * NC + GPT_C_POST1];
+  p.c2 = coef[tb * NC + GPT_C_POST2];
+  p.sigma = tb != 0 ? expf(0.5f * coef[tb * NC + GPT_C_LOGVAR]) : 0.f;
+  p.recip = coef[tb * NC + GPT_C_RECIP];
+  p.recipm1 = coef[tb * NC + GPT_C_RECIPM1];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < DV; i += gridDim.x * blockDim.x) {
+    const int64_t o = ((int64_t)b * DV + i) * V;
+    const vec<V> m = vload<V>(mo + o), x = vload<V>(xt + o);
+    float z[4];
+    philox_normals4(o >> 2, seed, sid, z);
+    vec<V> r;
+    float x0;
+#pragma unroll
+    for (int e = 0; e < V; ++e) r.v[e] = post_one(m.v[e], x.v[e], z[(V == 4 ? 0 : (int)(o & 3)) + e], p, predict_xstart, use_clamp, lo, hi, &x0);
+    vstore<V>(xout + o, r);
   }
 }
 
@@ -198,35 +255,11 @@ __global__ __launch_bounds__(256) void mse_rows_bwd_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------- Philox4x32-10 -> N(0,1) by Box-Muller
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
-  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
-  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-
 __global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t sid) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one Philox block -> 4 normals
   if (q * 4 >= n) return;
-  uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)sid, (uint32_t)(sid >> 32)};
-  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    philox_round(c, k0, k1);
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
   float z[4];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
-    const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float rad = sqrtf(-2.0f * logf(u1));
-    float sn, cs;
-    sincosf(6.28318530717958647692f * u2, &sn, &cs);
-    z[2 * h] = rad * cs;
-    z[2 * h + 1] = rad * sn;
-  }
+  philox_normals4(q, seed, sid, z);
 #pragma unroll
   for (int e = 0; e < 4; ++e)
     if (q * 4 + e < n) out[q * 4 + e] = z[e];
@@ -336,6 +369,24 @@ extern "C" int gpt_posterior_step(const float* model_out, const float* x_t, cons
   else POST(1);
 #undef POST
   return gpt_launch_status("gpt_posterior_step");
+}
+
+int gpt_posterior_step_philox(const float* model_out, const float* x_t, int64_t t, const float* coef, int predict_xstart, int use_clamp,
+                              float lo, float hi, uint64_t seed, uint64_t sid, float* x_out, int B, int D, void* stream) {
+  GPT_REQUIRE(model_out && x_t && coef && x_out && t >= 0, "gpt_sample_loop: posterior step: null operand");
+  GPT_REQUIRE(B > 0 && D > 0, "gpt_sample_loop: posterior step: empty problem (B=%d D=%d)", B, D);
+  const int V = vec_width(D, model_out, x_t, x_out, nullptr, nullptr);
+  const int gx = blocks_for(D / V) > 8 ? 8 : blocks_for(D / V);
+  const dim3 grid(gx, B);
+  hipStream_t s = (hipStream_t)stream;
+#define POSTP(VV)                                                                                                          \
+  hipLaunchKernelGGL(posterior_philox_kernel<VV>, grid, dim3(256), 0, s, model_out, x_t, t, coef, predict_xstart, use_clamp, lo, hi, \
+                     seed, sid, x_out, B, D / VV)
+  if (V == 4) POSTP(4);
+  else if (V == 2) POSTP(2);
+  else POSTP(1);
+#undef POSTP
+  return gpt_launch_status("gpt_sample_loop: posterior step");
 }
 
 extern "C" int gpt_ddim_step(const float* model_out, const float* x_t, const float* noise, const int64_t* t,

@@ -144,11 +144,20 @@ static int sample_loop(const char* who, int ddim, float eta, const float* alphas
               "%s: bad step range [%d..%d] of %d", who, first_step, last_step, n_steps);
   GPT_REQUIRE(ws->layer_stride == 0, "%s: needs an inference workspace", who);
   const int64_t BD = (int64_t)B * m->D;
+  static const bool fuse_noise = [] {
+    const char* e = getenv("GPT_POST_PHILOX");   // 0: gpt_randn + gpt_posterior_step as separate launches (cross-check, A/B)
+    return !e || atoi(e) != 0;
+  }();
   for (int i = first_step; i >= last_step; --i) {
-    CHECK(gpt_fill_i64(t_index, B, i, stream));
     CHECK(gpt_fill_i64(t_model, B, host_timestep_map[i], stream));
     // x_prev and the losses are the loop's constants: their tokens are encoded in the first step only
     CHECK(denoiser_forward(m, ws, x, t_model, loss_target, loss_prev, loss_is_f64, x_prev, model_out, B, i != first_step, stream));
+    if (!ddim && !noise && fuse_noise) {
+      // DDPM with in-kernel noise: Philox + posterior update in one kernel, the timestep as a scalar
+      CHECK(gpt_posterior_step_philox(model_out, x, i, coef, predict_xstart, use_clamp, lo, hi, seed, (uint64_t)i, x, B, m->D, stream));
+      continue;
+    }
+    CHECK(gpt_fill_i64(t_index, B, i, stream));
     const float* nz = nullptr;
     if (need_noise) {
       nz = noise ? noise + (int64_t)i * BD : noise_buf;

@@ -511,6 +511,26 @@ def test_sampled_mlp_downstream_loss_within_1pct(golden, dtype):
     assert rel < 1e-2, (rel, loss_got.tolist(), loss_ref.tolist())
 
 
+@pytest.mark.parametrize("case,px,clip", [("mnist_small", True, False), ("cifar_small", False, True), ("cartpole_small", True, False)])
+def test_seeded_loop_equals_injected_philox_noise(case, px, clip):
+    """The DDPM loop with in-kernel noise (Philox drawn inside the posterior kernel, timestep as a scalar) is bit-identical to the
+    same loop fed the buffers gpt_randn writes for stream (seed, i): D % 4 == 0 (16-byte groups = whole Philox blocks), D % 4 == 2
+    (cifar: 8-byte groups, half blocks) and an odd row width (cartpole, D = 1250: rows start inside a block)."""
+    m, plan, sd = build(case, "fp32")
+    m.predict_xstart = px
+    diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=px, noise_schedule="linear", steps=1000, timestep_respacing="20")
+    n, B, seed = diff.num_timesteps, 5, 987654321
+    _, _, lt, lp, xp = make_inputs(case, B=B, seed=31)
+    noise = torch.empty(n, B, plan.D, device=DEV)
+    for i in range(n):
+        L.check(L.lib().gpt_randn(L.ptr(noise[i]), B * plan.D, seed, i, L.stream()), "gpt_randn")
+    kw = dict(loss_target=lt.to(DEV), loss_prev=lp.to(DEV), x_prev=xp.to(DEV))
+    start = step_noise(77, -1, B, plan.D).to(DEV)
+    a = diff.p_sample_loop(m, (B, plan.D), noise=start.clone(), clip_denoised=clip, model_kwargs=kw, device="cuda", seed=seed)
+    b = diff.p_sample_loop(m, (B, plan.D), noise=start.clone(), clip_denoised=clip, model_kwargs=kw, device="cuda", step_noise=noise)
+    assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+
+
 @pytest.mark.parametrize("case,resp,tag,eta,px,clip", [
     ("mnist_small", "ddim25", "ddim25_eta0", 0.0, True, False), ("mnist_small", "50", "r50_eta05", 0.5, True, False),
     ("cifar_small", "ddim25", "ddim25_eta1_eps_clip", 1.0, False, True)])

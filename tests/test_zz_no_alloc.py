@@ -34,6 +34,16 @@ def _run(fn, A, W, bias, R, epi):
 
 
 def test_static_scratch_entry_point_matches_workspace_entry_point():
+    try:
+        _static_against_workspace()
+    finally:
+        # leave the process as the other tests expect it: the engines' K-span workspace registered again (the body below
+        # unregisters it; an engine built earlier would silently take the single-pass kernels otherwise - ADVICE r02)
+        L._gemm_ws.pop(torch.device(DEV).index, None)
+        L.ensure_gemm_workspace(torch.device(DEV))
+
+
+def _static_against_workspace():
     lib = L.lib()
     ws = torch.empty(SCRATCH, dtype=torch.uint8, device=DEV)
     # two calls in a row, the second smaller (it finds the first call's partial tiles in the scratch and must not read them);

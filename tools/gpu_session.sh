@@ -1,19 +1,13 @@
 set -o pipefail
 mkdir -p gpurun_out
-L=gpurun_out/r3_new.log
-timeout -k 10 900 python -u -m pytest -x -q -m gpu --timeout 400 --timeout-method thread -s \
-  "tests/test_hip_parity.py::test_actor_permutation_maps_bit_exact" "tests/test_hip_parity.py::test_cartpole_full_size_forward_vs_oracle" \
-  "tests/test_hip_parity.py::test_forward_golden_fp32" "tests/test_hip_parity.py::test_forward_oracle_bf16" \
-  "tests/test_hip_parity.py::test_permutation_maps_bit_exact" > $L 2>&1; rc=$?
-grep -E "^\[|passed|failed|Error|error" $L | grep -v Gloo | cut -c1-400 | tail -30
-if grep -q "HSA_STATUS_ERROR\|Memory access fault" $L; then echo FAULT; exit 1; fi
-[ $rc -eq 0 ] || exit $rc
-S0=$(date +%s); timeout -k 10 700 python bench.py > gpurun_out/r3_bench1.json 2> gpurun_out/r3_bench1.err || { tail -20 gpurun_out/r3_bench1.err; exit 1; }
-echo "bench wall: $(( $(date +%s) - S0 )) s"
+timeout -k 10 1500 python -u -m pytest tests -x -q -m gpu --timeout 400 --timeout-method thread > gpurun_out/r3_gpu_all.log 2>&1; rc=$?; tail -3 gpurun_out/r3_gpu_all.log | cut -c1-300
+if grep -q "HSA_STATUS_ERROR\|Memory access fault" gpurun_out/r3_gpu_all.log; then echo FAULT; exit 1; fi
+[ $rc -eq 0 ] || { grep -E "^E |Error" gpurun_out/r3_gpu_all.log | head -20; exit $rc; }
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1 || { tail -5 gpurun_out/smoke.log; exit 1; }
+tail -1 gpurun_out/smoke.log
+timeout -k 10 300 python bench.py --no-train --no-cpu-baseline > gpurun_out/r3_bench2.json 2> gpurun_out/r3_bench2.err || { tail -20 gpurun_out/r3_bench2.err; exit 1; }
 python - <<'PY'
 import json
-d=json.load(open('gpurun_out/r3_bench1.json'))
-print('headline', d['value'], d['ms_per_step'], d['roofline']['frac'])
-for k in ('fp32','b64','cifar','train','train_weak','cifar_big','cpu_baseline_train','cpu_baseline'):
-    print(k, json.dumps(d.get(k))[:700])
+d=json.load(open('gpurun_out/r3_bench2.json'))
+print('headline', d['value'], d['ms_per_step'], d['roofline']['frac'], 'b64', d['b64']['ms_per_step'], 'cifar', d['cifar']['ms_per_step'])
 PY
