@@ -625,6 +625,20 @@ double cost_rows224(const GemmArgs<T>& g) {
   return rounds * 0.90 + 0.02;
 }
 
+// 192-row tiles (bf16): ONE round only, for small problems whose 224- / 256-row tiles leave a quarter of the CUs idle
+// (B = 64 sampling, fc1: M = 1664, N = 6144 -> 216 tiles of 3/4 the main-loop work instead of 192 of 7/8)
+template <typename T>
+double cost_rows192(const GemmArgs<T>& g) {
+  static const bool enabled = [] {
+    const char* e = getenv("GPT_GEMM_192");    // 0 disables (A/B measurements)
+    return !e || atoi(e) != 0;
+  }();
+  if (!enabled || sizeof(T) != 2) return 1e30;
+  const int tiles = ((g.M + 191) / 192) * ((g.N + 255) / 256);
+  if (tiles > n_cus()) return 1e30;
+  return 0.80 + 0.02;
+}
+
 template <typename T>
 int dispatch(const GemmArgs<T>& g, int epi, hipStream_t s) {
   const int tiles256 = ((g.M + 255) / 256) * ((g.N + 255) / 256);
@@ -653,7 +667,9 @@ int dispatch(const GemmArgs<T>& g, int epi, hipStream_t s) {
     int rt = 8;
     if (tile_mode() == 0) {
       const double c8 = plan_rows256(g, &m_main);
-      if (cost_rows224(g) < c8 - 0.01) { rt = 7; m_main = g.M; }
+      double best = c8;
+      if (cost_rows224(g) < best - 0.01) { rt = 7; m_main = g.M; best = cost_rows224(g); }
+      if (cost_rows192(g) < best - 0.01) { rt = 6; m_main = g.M; }
     }
     GemmArgs<T> head = g;
     head.M = m_main;

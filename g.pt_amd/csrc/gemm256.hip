@@ -68,7 +68,7 @@ __device__ __forceinline__ u32x4 frag(const char* half, int row, int lc) {
 // rows per wave-row (their sources are clamped to valid rows).
 template <typename T, int EPI, int RT>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs<T> g) {
-  static_assert(RT == 8 || ((RT == 7 || RT == 4) && sizeof(T) == 2), "224- and 128-row tiles exist for the 16x16x32 bf16 path only");
+  static_assert(RT == 8 || ((RT == 7 || RT == 6 || RT == 4) && sizeof(T) == 2), "224-, 192- and 128-row tiles exist for the 16x16x32 bf16 path only");
   constexpr int BM = 32 * RT, WROWS = 16 * RT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -359,9 +359,11 @@ int dispatch256(const GemmArgs<T>& g, int epi, hipStream_t s) {
 
 }  // namespace
 
-// rt = 16-row tiles per wave: 8 (256-row block tiles) or 7 (224-row)
+// rt = 16-row tiles per wave: 8 (256-row block tiles), 7 (224-row), 6 (192-row: M = 1664 = 8.67 x 192 puts 216 tiles of
+// 3/4 the work on the chip where 224-row tiles put 192 of 7/8, the last of them nearly empty) or 4 (128-row)
 int gemm256_bf16(const GemmArgs<bf16_t>& g, int epi, int rt, hipStream_t s) {
   if (rt == 4) return dispatch256<bf16_t, 4>(g, epi, s);
+  if (rt == 6) return dispatch256<bf16_t, 6>(g, epi, s);
   return rt == 7 ? dispatch256<bf16_t, 7>(g, epi, s) : dispatch256<bf16_t, 8>(g, epi, s);
 }
 int gemm256_f32(const GemmArgs<float>& g, int epi, hipStream_t s) { return dispatch256<float, 8>(g, epi, s); }

@@ -52,7 +52,9 @@ def build(case, dtype="fp32", seed=0):
                                    # 128 x 256 tiles (gemm128.hip: few 256-row tiles, one 128-row tile per CU), also ragged in M and N
                                    (1664, 4608, 192), (1650, 4600, 192),
                                    # one round of 256-row tiles + a row tail that is one round of the 128 x 256 kernel
-                                   (3328, 6144, 128), (3300, 6136, 128)])
+                                   (3328, 6144, 128), (3300, 6136, 128),
+                                   # one round of 192-row tiles (216 of them; B = 64 sampling's fc1), also ragged in M and N
+                                   (1664, 6144, 128), (1650, 6136, 192)])
 def test_gemm_epilogues(dtype, tol, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
     A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05

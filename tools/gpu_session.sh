@@ -1,13 +1,9 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 1500 python -u -m pytest tests -x -q -m gpu --timeout 400 --timeout-method thread > gpurun_out/r3_gpu_all.log 2>&1; rc=$?; tail -3 gpurun_out/r3_gpu_all.log | cut -c1-300
-if grep -q "HSA_STATUS_ERROR\|Memory access fault" gpurun_out/r3_gpu_all.log; then echo FAULT; exit 1; fi
-[ $rc -eq 0 ] || { grep -E "^E |Error" gpurun_out/r3_gpu_all.log | head -20; exit $rc; }
-timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1 || { tail -5 gpurun_out/smoke.log; exit 1; }
-tail -1 gpurun_out/smoke.log
-timeout -k 10 300 python bench.py --no-train --no-cpu-baseline > gpurun_out/r3_bench2.json 2> gpurun_out/r3_bench2.err || { tail -20 gpurun_out/r3_bench2.err; exit 1; }
-python - <<'PY'
-import json
-d=json.load(open('gpurun_out/r3_bench2.json'))
-print('headline', d['value'], d['ms_per_step'], d['roofline']['frac'], 'b64', d['b64']['ms_per_step'], 'cifar', d['cifar']['ms_per_step'])
-PY
+timeout -k 10 300 python -u -m pytest -x -q -m gpu --timeout 200 --timeout-method thread tests/test_hip_parity.py::test_gemm_epilogues 2>&1 | tail -2 || exit 1
+for v in 0 1 0 1; do
+  echo "GPT_GEMM_192=$v"; GPT_GEMM_192=$v timeout -k 10 120 python tools/gemm_bench.py --shapes fc1:1664:6144:1536:1 big:1768:12288:3072:1 2>&1 | grep -v amdgpu.ids | tail -4 || exit 1
+done
+for v in 0 1 0 1; do
+  echo "bench b64 GPT_GEMM_192=$v"; GPT_GEMM_192=$v timeout -k 10 200 python bench.py --batch 64 --steps 400 --warmup 40 --no-train --no-extra --no-cpu-baseline --no-roofline --repeats 3 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['spread']['ms_per_step_min'])" || exit 1
+done
