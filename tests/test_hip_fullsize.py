@@ -80,6 +80,29 @@ def test_full_size_training_gradients_vs_oracle(dtype, B, max_bar, cos_bar):
     print(f"[{dtype} B={B}] worst gradient tensor: {worst}")
 
 
+@pytest.mark.parametrize("dtype,B,max_bar,cos_bar", [("fp32", 8, 1e-3, 0.999999), ("bf16", 32, 3e-2, 0.999), ("bf16", 6, 3e-2, 0.999)])
+def test_cartpole_training_gradients_vs_oracle(dtype, B, max_bar, cos_bar):
+    """The third shipped task's token plan under training (configs/train/cartpole.yaml:38-46: layer_by_layer, 18 tokens of widths
+    1 ... 1024, heads of 128; reduced width 256): every gradient tensor against the oracle's autograd - the ragged encoder /
+    decoder gradients with one-column tokens (log_std, the output bias), M = 18 B rows on the grouped TN route (B = 32: 576 rows)
+    and on the transpose + NT route (B = 6: 108 rows)."""
+    from gpt_amd.trainstep import TrainStep
+    case = "cartpole_small"
+    m, plan, sd = build(case, dtype, seed=25)
+    m.train()
+    diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
+    cpu = _train_inputs(case, B, seed=700 + B)
+    ref_loss, ref_mse, ref = _oracle_grads(sd, plan, *cpu)
+    xp, x_start, lp, lt, t, noise = (v.to(DEV) for v in cpu)
+    ts = TrainStep(m, diff, lr=2e-4, wd=0.1, grad_clip=0.0, use_ema=False)
+    mse = ts.loss_and_grads(xp, x_start, lp, lt, t, noise=noise)
+    torch.cuda.synchronize()
+    tol = 2e-4 if dtype == "fp32" else 2e-2
+    assert abs(float(mse.mean()) - ref_loss) < tol * ref_loss
+    worst = _compare_grads({k: p.grad for k, p in m.named_parameters()}, ref, max_bar, cos_bar)
+    print(f"[cartpole_small {dtype} B={B}] worst gradient tensor: {worst}")
+
+
 def test_full_size_training_through_autograd_bridge_vs_oracle():
     """The reference's own call sequence (main.py:47-67: training_losses(...)['loss'].mean().backward()) at d = 1536 in bf16:
     the DenoiseFunction bridge must deliver the same gradients as the oracle (B = 32)."""
