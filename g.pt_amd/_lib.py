@@ -116,6 +116,7 @@ _PROTOS = {
                             i32, vp], i32),
     "gpt_pack_segments": ([vp, vp, i32, vp, i32, i64, vp], i32),
     "gpt_pack_tensors": ([vp, i32, i64, vp], i32),
+    "gpt_pack_tensors_if_changed": ([vp, i32, i64, vp, vp], i32),
     "gpt_dp_unique_id": ([vp], i32),
     "gpt_dp_init": ([vp, i32, i32], i32),
     "gpt_dp_destroy": ([], i32),

@@ -147,7 +147,9 @@ __global__ __launch_bounds__(OPT_THREADS) void pack_kernel(const float* __restri
 
 // Multi-tensor variant for parameters that do NOT live in one arena (the checkpoint-layout nn.Module of the reference: 235
 // separate tensors): item i covers 16-byte groups [first4, next item's first4) of a virtual concatenation.
-__global__ __launch_bounds__(OPT_THREADS) void pack_tensors_kernel(const gpt_pack_item_t* __restrict__ items, int n_items, int64_t n4) {
+__global__ __launch_bounds__(OPT_THREADS) void pack_tensors_kernel(const gpt_pack_item_t* __restrict__ items, int n_items, int64_t n4,
+                                                                   const unsigned long long* __restrict__ changed) {
+  if (changed && *changed == 0ull) return;          // gpt_pack_tensors_if_changed: the sources are what the last pack saw
   const int64_t i4 = (int64_t)blockIdx.x * OPT_THREADS + threadIdx.x;
   if (i4 >= n4) return;
   int lo = 0, hi = n_items - 1;
@@ -175,13 +177,60 @@ __global__ __launch_bounds__(OPT_THREADS) void pack_tensors_kernel(const gpt_pac
   write_packed(it.dst, it.dst_dtype, sg, r, v);
 }
 
+// Position-sensitive 64-bit checksum of every source element of a pack table: sum over the fp32 words of bits x (2 x global
+// word index + 1) mod 2^64 (an odd multiplier is invertible, so any single changed word changes the sum).  One row of workgroups
+// per item streams that item's 16-byte groups; wave sums by shuffles, one 64-bit vector atomic per wave.
+constexpr int CKS_BLOCKS = 48;
+__global__ __launch_bounds__(OPT_THREADS) void pack_checksum_kernel(const gpt_pack_item_t* __restrict__ items, unsigned long long* __restrict__ acc) {
+  const gpt_pack_item_t it = items[blockIdx.y];
+  const int64_t n4 = it.count >> 2;
+  unsigned long long h = 0;
+  for (int64_t i = (int64_t)blockIdx.x * OPT_THREADS + threadIdx.x; i < n4; i += (int64_t)CKS_BLOCKS * OPT_THREADS) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(it.src + 4 * i);
+    const unsigned long long w = 8ull * (unsigned long long)(it.first4 + i) + 1ull;
+    h += v[0] * w + v[1] * (w + 2) + v[2] * (w + 4) + v[3] * (w + 6);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (it.count & 3)) {     // ragged tail (count % 4 elements)
+    const int64_t j = (n4 << 2) + threadIdx.x;
+    h += (unsigned long long)__float_as_uint(it.src[j]) * (2ull * (unsigned long long)(4 * it.first4 + j) + 1ull);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned int lo = __shfl_xor((unsigned int)h, o, 64), hi = __shfl_xor((unsigned int)(h >> 32), o, 64);
+    h += ((unsigned long long)hi << 32) | lo;
+  }
+  if ((threadIdx.x & 63) == 0 && h) atomicAdd(acc, h);
+}
+
+// state[0] = running sum (zero on entry), [1] = the sum the last pack saw, [2] = "changed" flag for the pack kernel, [3] = valid
+__global__ void pack_decide_kernel(unsigned long long* __restrict__ state) {
+  if (threadIdx.x == 0) {
+    state[2] = (state[3] == 0ull || state[0] != state[1]) ? 1ull : 0ull;
+    state[1] = state[0];
+    state[0] = 0ull;
+    state[3] = 1ull;
+  }
+}
+
 }  // namespace
 
 extern "C" int gpt_pack_tensors(const gpt_pack_item_t* items, int n_items, int64_t n4, void* stream) {
   GPT_REQUIRE(items && n_items > 0 && n4 > 0, "gpt_pack_tensors: bad operands");
   const int64_t blocks = (n4 + OPT_THREADS - 1) / OPT_THREADS;
-  hipLaunchKernelGGL(pack_tensors_kernel, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, (hipStream_t)stream, items, n_items, n4);
+  hipLaunchKernelGGL(pack_tensors_kernel, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, (hipStream_t)stream, items, n_items, n4,
+                     (const unsigned long long*)nullptr);
   return gpt_launch_status("gpt_pack_tensors");
+}
+
+extern "C" int gpt_pack_tensors_if_changed(const gpt_pack_item_t* items, int n_items, int64_t n4, uint64_t* state, void* stream) {
+  GPT_REQUIRE(items && n_items > 0 && n_items <= 65535 && n4 > 0 && state && ((uintptr_t)state % 8) == 0, "gpt_pack_tensors_if_changed: bad operands");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned long long* st = reinterpret_cast<unsigned long long*>(state);
+  hipLaunchKernelGGL(pack_checksum_kernel, dim3(CKS_BLOCKS, n_items), dim3(OPT_THREADS), 0, s, items, st);
+  hipLaunchKernelGGL(pack_decide_kernel, dim3(1), dim3(64), 0, s, st);
+  const int64_t blocks = (n4 + OPT_THREADS - 1) / OPT_THREADS;
+  hipLaunchKernelGGL(pack_tensors_kernel, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, s, items, n_items, n4, (const unsigned long long*)(st + 2));
+  return gpt_launch_status("gpt_pack_tensors_if_changed");
 }
 
 extern "C" int gpt_grad_sumsq(const float* grads, int64_t n, float* scratch, float* out, void* stream) {

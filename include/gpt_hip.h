@@ -495,6 +495,12 @@ typedef struct {
   int32_t k, ld, dst_dtype, reserved;
 } gpt_pack_item_t;
 int gpt_pack_tensors(const gpt_pack_item_t* items, int n_items, int64_t n4, void* stream);
+/* The same, skipped ON THE DEVICE when no source element changed since the last call with this `state` (4 x uint64 of device
+ * memory, zero before the first call; no host synchronisation): a streaming 64-bit position-sensitive checksum of all sources
+ * (read only: a third of the pack's bytes) decides whether the pack kernel does anything.  For callers that run the model in a
+ * host loop (the reference's per-step p_sample_loop_progressive, gaussian_diffusion.py:458-505: 1000 forwards over weights that
+ * do not change).  The destinations must not have been written by anyone else in between. */
+int gpt_pack_tensors_if_changed(const gpt_pack_item_t* items, int n_items, int64_t n4, uint64_t* state, void* stream);
 
 #ifdef __cplusplus
 }

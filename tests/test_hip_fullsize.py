@@ -287,6 +287,20 @@ def test_ema_updated_through_dot_data_is_not_stale(dtype):
     tol = 2e-4 if dtype == "fp32" else 3e-2
     assert float((out - ref).abs().max()) / scale < tol
     assert float((stale - ref).abs().max()) / scale > 10 * tol                # the test can tell stale from fresh
+    # the pack is skipped on the device while a checksum of the parameters stands still (gpt_pack_tensors_if_changed): a second
+    # forward gives the same bits, and ONE element changed through .data (no version bump) must be seen by the next forward
+    with torch.no_grad():
+        again = ema(dev[0], dev[1], dev[2], loss_prev=dev[3], x_prev=dev[4]).cpu()
+    assert torch.equal(again, out)
+    w = ema.decoder.blocks[0].mlp[2].weight
+    w.data[3, 5] += 0.75 if dtype == "fp32" else 24.0
+    new_sd["decoder.blocks.0.mlp.2.weight"] = w.detach().cpu().clone()
+    with torch.no_grad():
+        out2 = ema(dev[0], dev[1], dev[2], loss_prev=dev[3], x_prev=dev[4]).cpu()
+        ref2 = od.forward(new_sd, plan, *cpu)
+    scale2 = float((ref2 - cpu[4]).abs().max())
+    assert float((ref2 - ref).abs().max()) / scale2 > 10 * tol, float((ref2 - ref).abs().max()) / scale2      # the edit matters ...
+    assert float((out2 - ref2).abs().max()) / scale2 < tol, float((out2 - ref2).abs().max()) / scale2          # ... and was packed
 
 
 def test_second_training_forward_before_backward_is_an_error():

@@ -1,12 +1,4 @@
 set -o pipefail
 mkdir -p gpurun_out
-S0=$(date +%s)
-GPT_BENCH_BACKEND=gloo GPT_BENCH_ONE_GPU=1 GPT_BENCH_WATCHDOG=1000 timeout -k 10 1100 python bench.py --gpus 2 --steps 20 --warmup 3 --repeats 2 > gpurun_out/r3_bench_n2.json 2> gpurun_out/r3_bench_n2.err; rc=$?
-echo "rc=$rc wall $(( $(date +%s) - S0 )) s"; tail -5 gpurun_out/r3_bench_n2.err | cut -c1-300
-python - <<'PY'
-import json
-d=json.loads([l for l in open('gpurun_out/r3_bench_n2.json') if l.startswith('{')][-1])
-print('n_gpus', d['n_gpus'], 'value', d['value'])
-for k in ('fp32','b64','cifar','train','train_weak','cifar_big'):
-    v=d.get(k); print(k, json.dumps({kk: v.get(kk) for kk in ('value','ms_per_step','error','global_batch','batch_per_gpu')}) if v else None)
-PY
+timeout -k 10 300 python -u -m pytest -x -q -m gpu --timeout 200 --timeout-method thread tests/test_hip_fullsize.py::test_ema_updated_through_dot_data_is_not_stale tests/test_hip_parity.py -k "ema_updated or forward or sampl" 2>&1 | grep -E "^E  |passed|failed" | head; 
+for v in 64 320; do timeout -k 10 200 python tools/compat_step_bench.py $v 2>&1 | grep "ms per step" || exit 1; done
