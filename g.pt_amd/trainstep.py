@@ -250,7 +250,10 @@ class TrainStep:
 
     @torch.no_grad()
     def sync_params(self):
-        """fp32 parameters of the other ranks' shards (bf16 compute mode gathers only the bf16 operands per step)."""
+        """fp32 parameters of the other ranks' shards (bf16 compute mode gathers only the bf16 operands per step).
+        A COLLECTIVE under the sharded step when the shards are stale: every rank must call it (and so everything that
+        calls it: state_dict() of the model, a re-pack of the engine) at the same point; a rank-0-only checkpoint is preceded
+        by sync_params() / sync_ema() on all ranks."""
         self.join()
         if self.shard:
             self._wait_operands()
