@@ -186,6 +186,53 @@ def cpu_baseline_train(case, iters=3):
                       f"{dt:.2f} s each; the GPU `train_weak` object runs B=128 per step", "final_loss": loss}
 
 
+def hbm_kernels(case, B, device):
+    """Achieved HBM GB/s of the elementwise kernels of one sampling step at the headline shapes (north_star: 'achieved HBM GB/s for
+    the elementwise kernels'), each timed alone with events around 48 back-to-back launches on the current stream that rotate over four operand sets; algorithmic
+    bytes per launch as DESIGN.md section 4 states them; peak = 8 TB/s (MI355X_MICROARCH.md)."""
+    c = CASES[case]
+    d, H, T, D = c["n_embd"], c["n_head"], 26, sum(c["parameter_sizes"])
+    M = B * T
+    lib, st = L.lib(), L.stream()
+    NS = 4          # operand sets used in rotation (0.3 - 0.4 GB together): a launch must not find its operands in the 256 MB Infinity Cache
+    gam, bet = torch.ones(d, device=device), torch.zeros(d, device=device)
+    xs = [torch.randn(M, d, device=device) for _ in range(NS)]
+    ys = [torch.empty(M, d, dtype=torch.bfloat16, device=device) for _ in range(NS)]
+    qkvs = [torch.randn(M, 3 * d, device=device).bfloat16() for _ in range(NS)]
+    atts = [torch.empty(M, d, dtype=torch.bfloat16, device=device) for _ in range(NS)]
+    posts = [[torch.randn(B, D, device=device) for _ in range(3)] for _ in range(NS)]
+    t = torch.full((B,), 500, dtype=torch.long, device=device)
+    coef = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000).coef_table(device)
+    runs = {
+        "layernorm (fp32 row -> bf16 row)": (M * d * 6, lambda i: lib.gpt_layernorm(
+            L.ptr(xs[i]), L.ptr(gam), L.ptr(bet), None, 0, L.ptr(ys[i]), L.BF16, None, None, M, d, 1e-5, st)),
+        "attention (qkv -> heads' outputs)": (M * 3 * d * 2 + M * d * 2, lambda i: lib.gpt_attention(
+            L.BF16, L.ptr(qkvs[i]), L.ptr(atts[i]), B, T, H, d // H, st)),
+        "posterior update (model_out, x_t, noise -> x_{t-1})": (4 * B * D * 4, lambda i: lib.gpt_posterior_step(
+            L.ptr(posts[i][0]), L.ptr(posts[i][1]), L.ptr(posts[i][2]), L.ptr(t), L.ptr(coef), 1, 0, 0.0, 0.0, L.ptr(posts[i][1]), None,
+            B, D, st)),
+    }
+    out = {}
+    for name, (nbytes, fn) in runs.items():
+        res = {"bytes": nbytes}
+        # "cold": the four operand sets in rotation (every launch reads from HBM); "warm": one set again and again (the Infinity
+        # Cache holds it: in the sampling step these kernels read what the kernel before them just wrote, which lies in between)
+        for tag, ns in (("cold", NS), ("warm", 1)):
+            for i in range(NS):
+                L.check(fn(i % ns), name)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for i in range(48):
+                L.check(fn(i % ns), name)
+            b.record()
+            torch.cuda.synchronize()
+            us = a.elapsed_time(b) * 1e3 / 48
+            gbs = nbytes / (us * 1e-6) / 1e9
+            res[tag] = {"us": us, "achieved_GBps": gbs, "frac_of_8TBps": gbs / 8000.0}
+        out[name] = res
+    return out
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher in front: one fresh child process per GPU, as the reference starts its own
     ranks (main.py:344-354, start_processes).  This parent has made no GPU call (nothing above touches the device before
@@ -255,6 +302,8 @@ def main():
     else:
         line = bench_sample(args, device, world, rank)
         if not args.no_extra and (args.case, args.dtype) == ("mnist", "bf16"):
+            if rank == 0:
+                line["hbm_kernels"] = guarded(lambda: hbm_kernels(args.case, args.batch or 320, device), rank, line, "hbm_kernels", 60.0)
             line["fp32"] = secondary_sample(args, device, world, rank, line, "fp32", "mnist", "fp32", args.batch or 320, 20, 3)
             # configs[0] / [1] name 64 vectors: the small-batch leg of the same workload
             line["b64"] = secondary_sample(args, device, world, rank, line, "b64", "mnist", "bf16", 64, 100, 10)

@@ -1,4 +1,11 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 300 python -u -m pytest -x -q -m gpu --timeout 200 --timeout-method thread tests/test_hip_fullsize.py::test_ema_updated_through_dot_data_is_not_stale tests/test_hip_parity.py -k "ema_updated or forward or sampl" 2>&1 | grep -E "^E  |passed|failed" | head; 
-for v in 64 320; do timeout -k 10 200 python tools/compat_step_bench.py $v 2>&1 | grep "ms per step" || exit 1; done
+S0=$(date +%s); timeout -k 10 500 python bench.py > gpurun_out/r3_bench3.json 2> gpurun_out/r3_bench3.err || { tail -20 gpurun_out/r3_bench3.err; exit 1; }
+echo "bench wall: $(( $(date +%s) - S0 )) s"
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/r3_bench3.json'))
+print('headline', d['value'], d['ms_per_step'], d['roofline']['frac'])
+print(json.dumps(d['hbm_kernels'], indent=1))
+print('b64', d['b64']['ms_per_step'], 'train_weak', d['train_weak']['ms_per_step'], 'train', d['train']['ms_per_step'])
+PY
