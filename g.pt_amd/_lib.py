@@ -44,7 +44,7 @@ class Backward(C.Structure):
                [(n, vp) for n in ("g_pos_emb", "g_ln_in_w", "g_ln_in_b", "g_ln_f_w", "g_ln_f_b")] + \
                [("g_enc_w", vp * MAX_TOKENS), ("g_dec_w", vp * MAX_TOKENS)] + \
                [(n, vp) for n in ("g", "gt", "d_h", "d_qkv", "d_act", "tA", "tB", "d_tok")] + \
-               [("wgrad_overwrite", i32), ("wgrad_defer", i32), ("wgrad_sumsq", vp)]
+               [("wgrad_overwrite", i32), ("wgrad_defer", i32), ("wgrad_sumsq", vp), ("ln_partials", vp), ("ln_partials_bytes", i64)]
 
 
 class OptSegment(C.Structure):

@@ -129,7 +129,9 @@ def _scratch(eng, B, slots=1):
     s = dict(g=torch.empty(M, d, dtype=torch.float32, device=dev), gt=torch.empty(slots * M, d, dtype=td, device=dev),
              d_h=torch.empty(M, d, dtype=td, device=dev), d_qkv=torch.empty(slots * M, 3 * d, dtype=td, device=dev),
              d_act=torch.empty(slots * M, 4 * d, dtype=td, device=dev), tA=torch.empty(4 * d, Mp, dtype=td, device=dev),
-             tB=torch.empty(4 * d, Mp, dtype=td, device=dev), d_tok=torch.empty(M, d, dtype=torch.float32, device=dev))
+             tB=torch.empty(4 * d, Mp, dtype=td, device=dev), d_tok=torch.empty(M, d, dtype=torch.float32, device=dev),
+             # per-workgroup dgamma / dbeta / bias sums of every LayerNorm backward launch of a call (gpt_backward_t.ln_partials)
+             ln_partials=torch.empty((2 * dec.n_layer + 2) * 256 * 3 * d, dtype=torch.float32, device=dev))
     eng._bw_scratch = (B, s, slots)
     return s
 
@@ -188,6 +190,7 @@ def _descriptor(eng, buf, scratch, overwrite=False, defer=1, sumsq=None):
         bw.g_dec_w[j] = base + 4 * o
     for k, t in scratch.items():
         setattr(bw, k, L.ptr(t))
+    bw.ln_partials_bytes = scratch["ln_partials"].numel() * 4
     bw.wgrad_overwrite = int(overwrite)
     bw.wgrad_defer = int(defer)
     bw.wgrad_sumsq = L.ptr(sumsq) if sumsq is not None else None

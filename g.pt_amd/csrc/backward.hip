@@ -42,7 +42,8 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const DyT
                                                             const float* __restrict__ gamma, const float* __restrict__ resid,
                                                             float* __restrict__ gout, OutT* __restrict__ gout_t,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            float* __restrict__ gcol, int rows, int d, int rows_per_block) {
+                                                            float* __restrict__ gcol, float* __restrict__ part, int rows, int d,
+                                                            int rows_per_block) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [LNB_WAVES][d]: the waves' partial dgamma, then dbeta, then gcol
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // gcol (optional): column sums of gout = the bias gradient of the Linear whose output gradient gout is (the launch is at most
@@ -111,6 +112,9 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const DyT
   // then each thread adds the 8 rows of its columns and issues the one global atomic per column - first dgamma, then dbeta
   // through the same buffer.  (LDS float atomics here - 48 ds_add_f32 per lane from 8 waves on the same addresses - were a
   // 12 us tail of every launch.)
+#ifdef GPT_LNB_NOFLUSH                               // diagnostic build only (results are garbage): the price of the flush below
+  if (rows > 0) return;
+#endif
   const int passes = gcol ? 3 : 2;                   // uniform over the grid
 #pragma unroll
   for (int pass = 0; pass < 3; ++pass) {
@@ -123,11 +127,16 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const DyT
     }
     __syncthreads();
     float* out = pass == 0 ? dgamma : pass == 1 ? dbeta : gcol;
+    // part != NULL: the workgroup's sums are STORED to its own row of a partials buffer [grid][3][d] (gpt_ln_partials_reduce adds
+    // them up later, in a fixed order): the 2 - 3 x d float atomics per workgroup on the same addresses were a third of this
+    // kernel's time at M = 3328 (22.6 us with them, 15.2 without)
+    float* prow = part ? part + ((int64_t)blockIdx.x * 3 + pass) * d : nullptr;
     for (int c = threadIdx.x; c < d; c += LNB_WAVES * 64) {
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < LNB_WAVES; ++w) t += red[w * d + c];
-      unsafeAtomicAdd(out + c, t);                 // hardware global_atomic_add_f32 (plain atomicAdd is a CAS loop)
+      if (prow) prow[c] = t;
+      else unsafeAtomicAdd(out + c, t);            // hardware global_atomic_add_f32 (plain atomicAdd is a CAS loop)
     }
   }
 }
@@ -772,6 +781,43 @@ extern "C" int gpt_layernorm_bwd(const void* dy, int dy_dtype, const float* x, c
 extern "C" int gpt_layernorm_bwd_colsum(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd,
                                         const float* gamma, const float* resid, float* gout, void* gout_t, int gout_t_dtype,
                                         float* dgamma, float* dbeta, float* gcol, int rows, int d, void* stream) {
+  return gpt_layernorm_bwd_part(dy, dy_dtype, x, mean, rstd, gamma, resid, gout, gout_t, gout_t_dtype, dgamma, dbeta, gcol, nullptr,
+                                nullptr, rows, d, stream);
+}
+
+// Sums of the partials buffers of up to GPT_LN_PART_MAX_CALLS layernorm backward launches: out[c] += sum_b part[b][k][c], blocks in
+// order (deterministic).  One launch for all of them: grid (column blocks, call x 3).
+namespace {
+__global__ __launch_bounds__(256) void ln_partials_reduce_kernel(LnPartCalls calls, int d) {
+  const int call = blockIdx.y / 3, k = blockIdx.y - 3 * call;
+  float* out = calls.c[call].out[k];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (!out || c >= d) return;
+  const float* p = calls.c[call].part + (int64_t)k * d + c;
+  const int nb = calls.c[call].nblocks;
+  const int64_t stride = 3 * (int64_t)d;
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+  int b = 0;
+  for (; b + 4 <= nb; b += 4) {          // four loads in flight per thread
+    t0 += p[(b + 0) * stride];
+    t1 += p[(b + 1) * stride];
+    t2 += p[(b + 2) * stride];
+    t3 += p[(b + 3) * stride];
+  }
+  for (; b < nb; ++b) t0 += p[b * stride];
+  out[c] += (t0 + t1) + (t2 + t3);
+}
+}  // namespace
+
+int gpt_ln_partials_reduce(const LnPartCalls& calls, int d, void* stream) {
+  if (calls.n == 0) return 0;
+  hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3((d + 255) / 256, calls.n * 3), dim3(256), 0, (hipStream_t)stream, calls, d);
+  return gpt_launch_status("gpt_layernorm_bwd: partials reduce");
+}
+
+int gpt_layernorm_bwd_part(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd, const float* gamma,
+                           const float* resid, float* gout, void* gout_t, int gout_t_dtype, float* dgamma, float* dbeta, float* gcol,
+                           float* part, int* n_blocks, int rows, int d, void* stream) {
   GPT_REQUIRE(dy && x && mean && rstd && gamma && gout && dgamma && dbeta, "gpt_layernorm_bwd: null operand");
   GPT_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 3072, "gpt_layernorm_bwd: bad sizes (need d %% 4 == 0, d <= 3072)");
   // every workgroup ends with one atomic per column on the SAME 2d addresses: their number, not the streaming, sets the tail
@@ -779,6 +825,7 @@ extern "C" int gpt_layernorm_bwd_colsum(const void* dy, int dy_dtype, const floa
   blocks = blocks > 256 ? 256 : blocks;
   const int rpb = (rows + blocks - 1) / blocks;
   const dim3 grid((rows + rpb - 1) / rpb), block(LNB_WAVES * 64);
+  if (n_blocks) *n_blocks = (int)grid.x;                      // rows of the partials buffer this launch fills (<= 256)
   const size_t lds = (size_t)LNB_WAVES * d * sizeof(float);   // <= 96 KiB at d = 3072
   hipStream_t s = (hipStream_t)stream;
   const bool dyb = dy_dtype == GPT_BF16, ob = gout_t_dtype == GPT_BF16;
@@ -795,7 +842,7 @@ extern "C" int gpt_layernorm_bwd_colsum(const void* dy, int dy_dtype, const floa
       attr_set = true;                                                                                                  \
     }                                                                                                                   \
     hipLaunchKernelGGL((layernorm_bwd_kernel<DY, OUT, NCH>), grid, block, lds, s, (const DY*)dy, x, mean, rstd, gamma, resid, \
-                       gout, (OUT*)gout_t, dgamma, dbeta, gcol, rows, d, rpb);                                              \
+                       gout, (OUT*)gout_t, dgamma, dbeta, gcol, part, rows, d, rpb);                                              \
   } while (0)
 #define LNB_T(NCH)                         \
   do {                                     \

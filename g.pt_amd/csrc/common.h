@@ -105,6 +105,23 @@ int gpt_tn_grouped_sumsq(int n, const void* const* P, const int64_t* ldp, const 
 int gpt_posterior_step_philox(const float* model_out, const float* x_t, int64_t t, const float* coef, int predict_xstart, int use_clamp,
                               float lo, float hi, uint64_t seed, uint64_t sid, float* x_out, int B, int D, void* stream);
 
+// gpt_layernorm_bwd_colsum with a partials buffer: part != NULL ([<= 256][3][d] floats) receives every workgroup's dgamma / dbeta /
+// gcol sums by plain stores instead of float atomics into the outputs, *n_blocks the number of rows written; the caller adds them up
+// with gpt_ln_partials_reduce (one launch for many layernorm launches, fixed order: reproducible sums)
+#define GPT_LN_PART_MAX_CALLS 28
+struct LnPartCalls {
+  struct {
+    const float* part;
+    float* out[3];     // dgamma, dbeta, gcol (NULL = none)
+    int nblocks;
+  } c[GPT_LN_PART_MAX_CALLS];
+  int n = 0;
+};
+int gpt_layernorm_bwd_part(const void* dy, int dy_dtype, const float* x, const float* mean, const float* rstd, const float* gamma,
+                           const float* resid, float* gout, void* gout_t, int gout_t_dtype, float* dgamma, float* dbeta, float* gcol,
+                           float* part, int* n_blocks, int rows, int d, void* stream);
+int gpt_ln_partials_reduce(const LnPartCalls& calls, int d, void* stream);
+
 // gpt_small_gemm_batched with one more (internal) argument: bf16_mma != 0 rounds both operands to bf16 and multiplies them on the
 // bf16 matrix pipe (the denoiser backward in bf16 compute mode); 0 = the exact-fp32 pipe
 int gpt_small_gemm_batched_mode(int n_problems, int a_dtype, const void* const* host_A, int64_t a_sm, int64_t a_sk, int b_dtype,

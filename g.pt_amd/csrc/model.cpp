@@ -231,6 +231,29 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
     const char* e = getenv("GPT_LNB_COLSUM");   // 0: bias gradients of mlp.2 / attn.proj by separate gpt_colsum launches (cross-check, A/B)
     return !e || atoi(e) != 0;
   }();
+  // LayerNorm backward: per-workgroup sums into bw->ln_partials where there is room (one reduce launch at the end of this call),
+  // float atomics otherwise
+  LnPartCalls ln_calls;
+  const int64_t ln_slot = 256 * 3 * (int64_t)d;                       // floats per launch
+  static const bool ln_part_on = [] {
+    const char* e = getenv("GPT_LNB_PARTIALS");   // 0: float atomics (cross-check, A/B)
+    return !e || atoi(e) != 0;
+  }();
+  auto ln_bwd = [&](const void* dy, int dy_dt, const float* xin, const float* mean, const float* rstd, const float* gamma,
+                    const float* resid, float* gout, void* gout_t, int gout_t_dt, float* dgamma, float* dbeta, float* gcol) -> int {
+    float* part = nullptr;
+    if (ln_part_on && bw->ln_partials && ln_calls.n < GPT_LN_PART_MAX_CALLS &&
+        (ln_calls.n + 1) * ln_slot * (int64_t)sizeof(float) <= bw->ln_partials_bytes)
+      part = bw->ln_partials + ln_calls.n * ln_slot;
+    int nb = 0;
+    CHECK(gpt_layernorm_bwd_part(dy, dy_dt, xin, mean, rstd, gamma, resid, gout, gout_t, gout_t_dt, dgamma, dbeta, gcol, part, &nb, M, d,
+                                 stream));
+    if (part) {
+      auto& c = ln_calls.c[ln_calls.n++];
+      c.part = part; c.out[0] = dgamma; c.out[1] = dbeta; c.out[2] = gcol; c.nblocks = nb;
+    }
+    return 0;
+  };
   auto wgrad = [&](const void* dY, int n_out, const void* X, int k_in, float* gW) -> int {
     // the TN kernel cuts the row range into spans when the weight has few 256 x 256 tiles (gemm256_tn.hip)
     if (use_tn && dt == GPT_BF16 && M % 64 == 0 && n_out % 256 == 0 && k_in % 256 == 0)
@@ -263,8 +286,8 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
   // bw->g / bw->gt = gradient of the residual stream behind the last Block = dY of its mlp.2: the bias gradient g_b2 is its column sum,
   // taken by the LayerNorm backward that produces it (and so for every Block below: ln1's backward of Block l + 1 feeds Block l's mlp.2,
   // ln2's backward feeds the attention projection of its own Block)
-  CHECK(gpt_layernorm_bwd_colsum(bw->d_tok, GPT_F32, xbuf(2 * L), stat(2 * L + 1, 0), stat(2 * L + 1, 1), m->ln_f_w, nullptr, bw->g, bw->gt,
-                                 dt, bw->g_ln_f_w, bw->g_ln_f_b, fuse_col && L > 0 ? bw->layers[L - 1].g_b2 : nullptr, M, d, stream));
+  CHECK(ln_bwd(bw->d_tok, GPT_F32, xbuf(2 * L), stat(2 * L + 1, 0), stat(2 * L + 1, 1), m->ln_f_w, nullptr, bw->g, bw->gt,
+               dt, bw->g_ln_f_w, bw->g_ln_f_b, fuse_col && L > 0 ? bw->layers[L - 1].g_b2 : nullptr));
   }
 
   // stages 1 .. L - the blocks, last to first (stage s = layer L - s)
@@ -321,8 +344,8 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
     if (!fuse_b1) CHECK(gpt_colsum(dt, d_act_l, 4 * d, gl.g_b1, M, 4 * d, stream));
     if (!grouped) CHECK(wgrad(d_act_l, 4 * d, h2, d, gl.g_w1));
     CHECK(gpt_gemm_nt(dt, d_act_l, 4 * d, gl.w1_t, 4 * d, nullptr, bw->d_h, d, nullptr, 0, M, d, 4 * d, GPT_EPI_STORE, stream));
-    CHECK(gpt_layernorm_bwd_colsum(bw->d_h, dt, xbuf(2 * l + 1), stat(2 + 2 * l, 0), stat(2 + 2 * l, 1), ly.ln2_w, bw->g, bw->g, gt2, dt,
-                                   gl.g_ln2_w, gl.g_ln2_b, fuse_col ? gl.g_bproj : nullptr, M, d, stream));
+    CHECK(ln_bwd(bw->d_h, dt, xbuf(2 * l + 1), stat(2 + 2 * l, 0), stat(2 + 2 * l, 1), ly.ln2_w, bw->g, bw->g, gt2, dt,
+                 gl.g_ln2_w, gl.g_ln2_b, fuse_col ? gl.g_bproj : nullptr));
     // attention output projection
     if (!fuse_col) CHECK(gpt_colsum(dt, gt2, d, gl.g_bproj, M, d, stream));
     if (!grouped) CHECK(wgrad(gt2, d, att, d, gl.g_wproj));
@@ -346,15 +369,16 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
       CHECK(wgrad(d_qkv_l, 3 * d, h1, d, gl.g_wqkv));
     }
     CHECK(gpt_gemm_nt(dt, d_qkv_l, 3 * d, gl.wqkv_t, 3 * d, nullptr, bw->d_h, d, nullptr, 0, M, d, 3 * d, GPT_EPI_STORE, stream));
-    CHECK(gpt_layernorm_bwd_colsum(bw->d_h, dt, xbuf(2 * l), stat(1 + 2 * l, 0), stat(1 + 2 * l, 1), ly.ln1_w, bw->g, bw->g, gt_next, dt,
-                                   gl.g_ln1_w, gl.g_ln1_b, fuse_col && l > 0 ? bw->layers[l - 1].g_b2 : nullptr, M, d, stream));
+    CHECK(ln_bwd(bw->d_h, dt, xbuf(2 * l), stat(1 + 2 * l, 0), stat(1 + 2 * l, 1), ly.ln1_w, bw->g, bw->g, gt_next, dt,
+                 gl.g_ln1_w, gl.g_ln1_b, fuse_col && l > 0 ? bw->layers[l - 1].g_b2 : nullptr));
   }
   CHECK(flush());                                        // what this call collected (gradients are complete when it returns)
-  if (stage_end < L + 2) return 0;
+  if (stage_end < L + 2) return gpt_ln_partials_reduce(ln_calls, d, stream);
   // stage L + 1 - position embedding: sum over the batch of the gradient of x0 = ln_in(enc) + pos_emb
   CHECK(gpt_colsum(GPT_F32, bw->g, (int64_t)T * d, bw->g_pos_emb, B, T * d, stream));
-  CHECK(gpt_layernorm_bwd(bw->g, GPT_F32, ws->enc, stat(0, 0), stat(0, 1), m->ln_in_w, nullptr, bw->d_tok, nullptr, GPT_F32,
-                          bw->g_ln_in_w, bw->g_ln_in_b, M, d, stream));
+  CHECK(ln_bwd(bw->g, GPT_F32, ws->enc, stat(0, 0), stat(0, 1), m->ln_in_w, nullptr, bw->d_tok, nullptr, GPT_F32,
+               bw->g_ln_in_w, bw->g_ln_in_b, nullptr));
+  CHECK(gpt_ln_partials_reduce(ln_calls, d, stream));
   {
     // dW_i[:, k] += sum_b d_tok[b, i, :] src_i[b, k]        (M = d, N = k_i, K = B); sources grouped by their row stride
     const int64_t ld_scal = (int64_t)m->n_scalar * W;

@@ -12,4 +12,4 @@ void gpt_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* gpt_last_error(void) { return g_err; }
-extern "C" int gpt_abi_version(void) { return 3; }
+extern "C" int gpt_abi_version(void) { return 4; }

@@ -361,6 +361,13 @@ typedef struct {
    * adds the sum of its squares here (the caller zeroes it before the backward): the Blocks' share of the squared gradient norm
    * that torch.nn.utils.clip_grad_norm_ (main.py:70) needs, taken from the accumulators instead of a second pass over 1.4 GB. */
   float* wgrad_sumsq;
+  /* ABI 4.  Optional scratch (NULL / 0: none) of ln_partials_bytes bytes: the LayerNorm backward launches of a call then STORE
+   * their per-workgroup dgamma / dbeta / bias-gradient sums there (256 x 3 x n_embd floats per launch) and ONE launch at the end of
+   * the call adds them to the gradients in a fixed order, instead of 2 - 3 n_embd float atomics per workgroup on the same
+   * addresses (a third of the kernel's time at 3328 rows).  Launches the buffer has no room for keep the atomics.  Full size:
+   * (2 n_layer + 2) x 256 x 3 x n_embd x 4 bytes. */
+  float* ln_partials;
+  int64_t ln_partials_bytes;
 } gpt_backward_t;
 
 /* Backward of gpt_denoiser_forward run on a layer_stride == 1 workspace: d_out[B, D] = dLoss/d(out).

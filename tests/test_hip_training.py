@@ -274,6 +274,42 @@ def test_fused_step_matches_torch_optimizer_tight_bar_in_the_deterministic_confi
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
 
 
+@pytest.mark.parametrize("dtype,B", [("fp32", 5), ("bf16", 32)])
+def test_layernorm_backward_partials_equal_atomics(monkeypatch, dtype, B):
+    """gpt_backward_t.ln_partials (ABI 4): the LayerNorm backward launches store per-workgroup dgamma / dbeta / bias sums and one
+    launch per call adds them up, against the float-atomics route (no buffer): every gradient equal to summation order, and the
+    partials route bit-reproducible from run to run in the tensors it produces."""
+    from gpt_amd import backward as gb
+    m, plan, sd = build("cifar_small", dtype, seed=19)
+    m.train()
+    x, t, lt, lp, xp = (v.to(DEV) for v in make_inputs("cifar_small", B=B, seed=61))
+    xx, tt, l1, l2, xpp = m._prepare(x, t, lt, lp, xp)
+    d_out = torch.randn(x.shape, generator=torch.Generator().manual_seed(3)).to(DEV) * 1e-2
+    orig = gb._descriptor
+
+    def without_partials(*a, **k):
+        bw, keep = orig(*a, **k)
+        bw.ln_partials, bw.ln_partials_bytes = None, 0
+        return bw, keep
+
+    bufs = []
+    for variant in ("partials", "partials", "atomics"):
+        monkeypatch.setattr(gb, "_descriptor", without_partials if variant == "atomics" else orig)
+        eng, ws, out = gb.forward_keep(m, xx, tt, l1, l2, xpp)
+        buf = torch.zeros(eng.arena.numel, device=DEV)
+        gb.backward_into(eng, ws, xx, xpp, d_out, buf)
+        torch.cuda.synchronize()
+        bufs.append({k: v.clone() for (k, _), v in zip(m.named_parameters(), eng.arena.views(buf, m))})
+    ln_like = [k for k in bufs[0] if ".ln" in k or "ln_" in k or k.endswith("mlp.2.bias") or k.endswith("attn.proj.bias")]
+    assert len(ln_like) >= 2 * (2 * plan.n_layer + 2)
+    for k in bufs[0]:
+        a, b, c = bufs[0][k], bufs[1][k], bufs[2][k]
+        scale = float(c.abs().max()) + 1e-30
+        assert float((a - c).abs().max()) <= 2e-5 * scale + 1e-12, k
+        if k in ln_like:
+            assert torch.equal(a, b), k                       # fixed summation order: the same bits every run
+
+
 def test_store_mode_weight_gradients_equal_accumulation(monkeypatch):
     """Where the grouped weight-gradient launch applies (bf16, B * T % 64 == 0, d % 256 == 0) TrainStep has the Blocks' weight
     gradients STORED and stops zeroing their part of the arena: three steps must give the parameters of the accumulate-into-zero

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/gpt_hip.h but not exported"
     assert declared == set(L.exported_symbols()), declared ^ set(L.exported_symbols())
-    assert lib.gpt_abi_version() == 3
+    assert lib.gpt_abi_version() == 4
 
 
 def test_token_plans_match_reference(golden):

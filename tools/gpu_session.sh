@@ -1,11 +1,6 @@
 set -o pipefail
 mkdir -p gpurun_out
-S0=$(date +%s); timeout -k 10 500 python bench.py > gpurun_out/r3_bench3.json 2> gpurun_out/r3_bench3.err || { tail -20 gpurun_out/r3_bench3.err; exit 1; }
-echo "bench wall: $(( $(date +%s) - S0 )) s"
-python - <<'PY'
-import json
-d=json.load(open('gpurun_out/r3_bench3.json'))
-print('headline', d['value'], d['ms_per_step'], d['roofline']['frac'])
-print(json.dumps(d['hbm_kernels'], indent=1))
-print('b64', d['b64']['ms_per_step'], 'train_weak', d['train_weak']['ms_per_step'], 'train', d['train']['ms_per_step'])
-PY
+timeout -k 10 600 python -u -m pytest -x -q -m gpu --timeout 300 --timeout-method thread tests/test_hip_training.py tests/test_hip_fullsize.py -k "not two_rank and not more_ranks and not ddp and not rccl" 2>&1 | grep -E "^E  |passed|failed" | head || exit 1
+for v in 0 1 0 1; do
+  echo "GPT_LNB_PARTIALS=$v"; GPT_LNB_PARTIALS=$v timeout -k 10 200 python bench.py --mode train --batch 128 --steps 40 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'])" || exit 1
+done
