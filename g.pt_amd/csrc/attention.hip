@@ -31,7 +31,7 @@ __device__ __forceinline__ int key_of(int reg, int half) { return (reg & 3) + 8 
 // leaves as 16-byte stores that cover whole rows of the head (HD * 2 contiguous bytes) instead of one 8-byte store per lane
 // and (row, 4 head-dims): 12 -> 5 store instructions per wave at HD = 96, every one made of full lines.
 template <typename T, int HD, bool OUT_LDS>
-__device__ __forceinline__ void attention_body(const T* __restrict__ qkv, T* __restrict__ y, int B, int Ttok, int n_head) {
+__device__ __forceinline__ void attention_body(const T* __restrict__ qkv, T* __restrict__ y, int B, int Ttok, int n_head, int Tout) {
   const int lane = threadIdx.x & 63;
   const int r = lane & 31, hh = lane >> 5;
   const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -174,8 +174,9 @@ __device__ __forceinline__ void attention_body(const T* __restrict__ qkv, T* __r
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    T* yb = y + (int64_t)b * Ttok * d + h * HD;
-    const int nchunk = Ttok * CPR;
+    // Tout < Ttok (the last Block of an inference forward): only the query rows the decoder reads are stored, compactly
+    T* yb = y + (int64_t)b * Tout * d + h * HD;
+    const int nchunk = Tout * CPR;
 #pragma unroll
     for (int i = 0; i < NVL; ++i) {
       const int c = lane + 64 * i, row = c / CPR, col = c - row * CPR;
@@ -184,8 +185,8 @@ __device__ __forceinline__ void attention_body(const T* __restrict__ qkv, T* __r
     return;
   }
   // O^T[dd][query r]: registers 4g..4g+3 are 4 consecutive head-dims -> one 8/16-byte store per group
-  if (rvalid) {
-    T* yr = y + ((int64_t)b * Ttok + r) * d + h * HD;
+  if (r < Tout) {
+    T* yr = y + ((int64_t)b * Tout + r) * d + h * HD;
 #pragma unroll
     for (int t = 0; t < ND; ++t) {
 #pragma unroll
@@ -205,23 +206,23 @@ __device__ __forceinline__ void attention_body(const T* __restrict__ qkv, T* __r
 }
 
 template <typename T, int HD, bool OUT_LDS>
-__global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ y, int B, int Ttok, int n_head) {
-  attention_body<T, HD, OUT_LDS>(qkv, y, B, Ttok, n_head);
+__global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ y, int B, int Ttok, int n_head, int Tout) {
+  attention_body<T, HD, OUT_LDS>(qkv, y, B, Ttok, n_head, Tout);
 }
 // at most 96 registers: 5 waves per SIMD = 20 per CU (B = 320, 16 heads: 5120 waves = exactly one round of 256 CUs)
 template <typename T, int HD, bool OUT_LDS>
-__global__ __launch_bounds__(256, 5) void attention_kernel_w5(const T* __restrict__ qkv, T* __restrict__ y, int B, int Ttok, int n_head) {
-  attention_body<T, HD, OUT_LDS>(qkv, y, B, Ttok, n_head);
+__global__ __launch_bounds__(256, 5) void attention_kernel_w5(const T* __restrict__ qkv, T* __restrict__ y, int B, int Ttok, int n_head, int Tout) {
+  attention_body<T, HD, OUT_LDS>(qkv, y, B, Ttok, n_head, Tout);
 }
 
 template <typename T>
-int launch(const void* qkv, void* y, int B, int T_, int n_head, int hd, hipStream_t s) {
+int launch(const void* qkv, void* y, int B, int T_, int n_head, int hd, int t_out, hipStream_t s) {
   const dim3 grid((B * n_head + 3) / 4), block(256);
   // variant (A/B measurements, GPT_ATT_VARIANT): bit 0 = output through LDS, bit 1 = 5 waves per SIMD.  Same box, B = 320,
   // HD = 96: 28.6 us (0) -> 23.2 (1) -> 24.3 (2) -> 21.0 (3).  HD = 128 keeps 4 waves per SIMD (its 40 KiB of LDS per workgroup
   // allow no more).
   static const int variant = [] { const char* e = getenv("GPT_ATT_VARIANT"); return e ? atoi(e) : 3; }();
-#define ATT_ARGS grid, block, 0, s, (const T*)qkv, (T*)y, B, T_, n_head
+#define ATT_ARGS grid, block, 0, s, (const T*)qkv, (T*)y, B, T_, n_head, t_out
 #define ATT(HD)                                                                                       \
   do {                                                                                                \
     if constexpr (HD <= 96) {                                                                         \
@@ -246,10 +247,16 @@ int launch(const void* qkv, void* y, int B, int T_, int n_head, int hd, hipStrea
 }  // namespace
 
 extern "C" int gpt_attention(int dtype, const void* qkv, void* y, int B, int T, int n_head, int hd, void* stream) {
+  return gpt_attention_rows(dtype, qkv, y, B, T, T, n_head, hd, stream);
+}
+
+// t_out <= T: only the first t_out query rows of every sample are stored, as a compact [B, t_out, d] tensor
+int gpt_attention_rows(int dtype, const void* qkv, void* y, int B, int T, int t_out, int n_head, int hd, void* stream) {
   GPT_REQUIRE(dtype == GPT_F32 || dtype == GPT_BF16, "gpt_attention: bad dtype %d", dtype);
+  GPT_REQUIRE(t_out > 0 && t_out <= T, "gpt_attention: stored rows %d out of range (T=%d)", t_out, T);
   GPT_REQUIRE(qkv && y, "gpt_attention: null operand");
   GPT_REQUIRE(B > 0 && T > 0 && T <= 32 && n_head > 0, "gpt_attention: need 0 < T <= 32 (B=%d T=%d H=%d)", B, T, n_head);
   GPT_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)y % 16) == 0, "gpt_attention: operands must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  return dtype == GPT_BF16 ? launch<bf16_t>(qkv, y, B, T, n_head, hd, s) : launch<float>(qkv, y, B, T, n_head, hd, s);
+  return dtype == GPT_BF16 ? launch<bf16_t>(qkv, y, B, T, n_head, hd, t_out, s) : launch<float>(qkv, y, B, T, n_head, hd, t_out, s);
 }

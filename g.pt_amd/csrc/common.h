@@ -122,6 +122,11 @@ int gpt_layernorm_bwd_part(const void* dy, int dy_dtype, const float* x, const f
                            float* part, int* n_blocks, int rows, int d, void* stream);
 int gpt_ln_partials_reduce(const LnPartCalls& calls, int d, void* stream);
 
+// gpt_attention storing only the first t_out query rows of every sample, compactly ([B, t_out, d]); gather of the matching fp32
+// residual rows (the pruned last Block of an inference forward, model.cpp)
+int gpt_attention_rows(int dtype, const void* qkv, void* y, int B, int T, int t_out, int n_head, int hd, void* stream);
+int gpt_gather_token_rows(const float* src, float* dst, int B, int T, int t_out, int d, void* stream);
+
 // gpt_small_gemm_batched with one more (internal) argument: bf16_mma != 0 rounds both operands to bf16 and multiplies them on the
 // bf16 matrix pipe (the denoiser backward in bf16 compute mode); 0 = the exact-fp32 pipe
 int gpt_small_gemm_batched_mode(int n_problems, int a_dtype, const void* const* host_A, int64_t a_sm, int64_t a_sk, int b_dtype,

@@ -78,6 +78,13 @@ static int denoiser_forward(const gpt_model_t* m, const gpt_workspace_t* ws, con
     return (void*)((char*)base + (keep ? (size_t)l * Mmax * width * es : 0));
   };
   auto stat = [&](int idx, int which) { return keep ? ws->stats + ((size_t)idx * 2 + which) * Mmax : (float*)nullptr; };
+  // inference only: the last Block behind its attention on the decoded tokens' rows alone (see there); needs the compact fp32
+  // residual rows to fit behind the compact activations in `act`: (T - To) * 4 * es >= To * 4
+  static const bool prune_on = [] {
+    const char* e = getenv("GPT_PRUNE_LAST");   // 0: all rows through the last Block (cross-check, A/B)
+    return !e || atoi(e) != 0;
+  }();
+  const bool prune = prune_on && !keep && L > 0 && m->n_out_tok < T && (size_t)(T - m->n_out_tok) * 4 * es >= (size_t)m->n_out_tok * 4;
 
   // ln_in + position embedding (transformer.py:226, 308-309)
   CHECK(gpt_layernorm(ws->enc, m->ln_in_w, m->ln_in_b, m->pos_emb, T, xbuf(0), GPT_F32, stat(0, 0), stat(0, 1), M, d, 1e-5f, stream));
@@ -98,6 +105,25 @@ static int denoiser_forward(const gpt_model_t* m, const gpt_workspace_t* ws, con
     void* act = lay(ws->act, l, 4 * (size_t)d);
     CHECK(wait_ready(ly.ready, stream));
     CHECK(gpt_gemm_nt(dt, h1, d, ly.wqkv, d, ly.bqkv, qkv, 3 * d, nullptr, 0, M, 3 * d, d, GPT_EPI_STORE, stream));
+    const bool last = l + 1 == L;
+    if (last && prune) {
+      // The decoder reads the first n_out_tok tokens only (transformer.py:237-240), and behind the last Block's attention rows
+      // do not mix any more: its projection, LayerNorms and MLP run on those rows alone, compacted to [B * To, d] (the attention
+      // kernel stores them so; the residual rows are gathered) - 15 of 26 tokens at the shipped plans = 58 % of 9/12 of the
+      // Block's FLOPs.  Same arithmetic per row; what changes is which kernel instance a GEMM of that height takes.
+      // (r01 measured +-0 for this at B = 320 on the kernels of the time; with gemm128.hip and the K-span passes: section 4.)
+      const int To = m->n_out_tok, Mc = B * To;
+      float* xc = reinterpret_cast<float*>((char*)ws->act + (size_t)Mc * 4 * d * es);   // the part of `act` the compact rows leave free
+      CHECK(gpt_attention_rows(dt, qkv, att, B, T, To, m->n_head, d / m->n_head, stream));
+      CHECK(gpt_gather_token_rows(xin, xc, B, T, To, d, stream));
+      CHECK(gpt_gemm_resadd_layernorm(dt, att, d, ly.wproj, d, ly.bproj, xc, d, xc, d, ly.ln2_w, ly.ln2_b, h2, nullptr, nullptr, Mc, d, d,
+                                      1e-5f, stream));
+      CHECK(gpt_gemm_nt(dt, h2, d, ly.w1, d, ly.b1, act, 4 * d, nullptr, 0, Mc, 4 * d, d, GPT_EPI_GELU, stream));
+      CHECK(gpt_gemm_resadd_layernorm(dt, act, 4 * d, ly.w2, 4 * d, ly.b2, xc, d, xc, d, m->ln_f_w, m->ln_f_b, ws->hf, nullptr, nullptr, Mc, d,
+                                      4 * d, 1e-5f, stream));
+      CHECK(wait_ready(m->dec_ready, stream));
+      return gpt_decode_tokens(dt, To, ws->hf, To, m->dec_w, m->dec_n, m->dec_off, x_prev, out, B, d, m->D, stream);
+    }
     CHECK(gpt_attention(dt, qkv, att, B, T, m->n_head, d / m->n_head, stream));
     CHECK(gpt_gemm_resadd_layernorm(dt, att, d, ly.wproj, d, ly.bproj, xin, d, xmid, d, ly.ln2_w, ly.ln2_b, h2, stat(2 + 2 * l, 0),
                                     stat(2 + 2 * l, 1), M, d, d, 1e-5f, stream));
@@ -107,9 +133,6 @@ static int denoiser_forward(const gpt_model_t* m, const gpt_workspace_t* ws, con
     } else {
       CHECK(gpt_gemm_nt(dt, h2, d, ly.w1, d, ly.b1, act, 4 * d, nullptr, 0, M, 4 * d, d, GPT_EPI_GELU, stream));
     }
-    // (Pruning the rows of the tokens the decoder does not read after the last block's attention was built and measured in
-    // r01: no gain at B = 320 - the compacted 3520-row GEMMs fall to the slower small-problem kernels.)
-    const bool last = l + 1 == L;
     const float* nw = last ? m->ln_f_w : m->layers[l + 1].ln1_w;
     const float* nb = last ? m->ln_f_b : m->layers[l + 1].ln1_b;
     void* nh = last ? ws->hf : lay(ws->h1, l + 1, d);

@@ -192,3 +192,28 @@ extern "C" int gpt_layernorm(const float* x, const float* gamma, const float* be
   if (out_dtype == GPT_F32) return launch<float>(x, gamma, beta, add, add_rows, y, mean, rstd, rows, d, eps, s);
   return launch<bf16_t>(x, gamma, beta, add, add_rows, y, mean, rstd, rows, d, eps, s);
 }
+
+// dst[b * t_out + r, :] = src[b * T + r, :] for r < t_out: the residual-stream rows of the tokens the decoder reads, compacted for
+// the pruned last Block of an inference forward (model.cpp).  fp32, d % 4 == 0, 16-byte aligned.
+namespace {
+__global__ __launch_bounds__(256) void gather_token_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int T, int t_out,
+                                                                int d4, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / d4;
+    const int c = (int)(i - row * d4);
+    const int64_t b = row / t_out;
+    const int r = (int)(row - b * t_out);
+    reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[(b * T + r) * d4 + c];
+  }
+}
+}  // namespace
+
+int gpt_gather_token_rows(const float* src, float* dst, int B, int T, int t_out, int d, void* stream) {
+  GPT_REQUIRE(src && dst && B > 0 && t_out > 0 && t_out <= T && d > 0 && d % 4 == 0, "gpt_gather_token_rows: bad arguments");
+  GPT_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "gpt_gather_token_rows: buffers must be 16-byte aligned");
+  const int64_t n4 = (int64_t)B * t_out * (d / 4);
+  const int64_t blocks = (n4 + 255) / 256;
+  hipLaunchKernelGGL(gather_token_rows_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, src, dst, T,
+                     t_out, d / 4, n4);
+  return gpt_launch_status("gpt_gather_token_rows");
+}

@@ -1,18 +1,10 @@
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 1500 python -u -m pytest tests -x -q -m gpu --timeout 400 --timeout-method thread > gpurun_out/r3_gpu_all.log 2>&1; rc=$?; tail -3 gpurun_out/r3_gpu_all.log | cut -c1-300
-if grep -q "HSA_STATUS_ERROR\|Memory access fault" gpurun_out/r3_gpu_all.log; then echo FAULT; exit 1; fi
-[ $rc -eq 0 ] || { grep -E "^E |Error" gpurun_out/r3_gpu_all.log | head -20; exit $rc; }
-timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1 || { tail -5 gpurun_out/smoke.log; exit 1; }
-tail -1 gpurun_out/smoke.log
-S0=$(date +%s); timeout -k 10 500 python bench.py > gpurun_out/r3_bench4.json 2> gpurun_out/r3_bench4.err || { tail -20 gpurun_out/r3_bench4.err; exit 1; }
-echo "bench wall: $(( $(date +%s) - S0 )) s"
-python - <<'PY'
-import json
-d=json.load(open('gpurun_out/r3_bench4.json'))
-print('headline', d['value'], d['ms_per_step'], d['roofline']['frac'])
-for k in ('fp32','b64','cifar','train','train_weak','cifar_big'):
-    v=d[k]; print(k, v.get('value'), v.get('ms_per_step'), (v.get('roofline') or {}).get('frac'), v.get('error'))
-print({k:(v['cold']['achieved_GBps'], v['warm']['achieved_GBps']) for k,v in d['hbm_kernels'].items()})
-print(d['cpu_baseline']['value'], d['cpu_baseline_train']['value'])
-PY
+timeout -k 10 900 python -u -m pytest -x -q -m gpu --timeout 300 --timeout-method thread tests/test_hip_parity.py tests/test_hip_chains.py tests/test_hip_fullsize.py -k "not training and not gradients" 2>&1 | grep -E "^E  |passed|failed" | head || exit 1
+for v in 0 1 0 1; do
+  echo "GPT_PRUNE_LAST=$v"; GPT_PRUNE_LAST=$v timeout -k 10 200 python bench.py --steps 300 --warmup 30 --no-train --no-extra --no-cpu-baseline --no-roofline --repeats 3 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['spread']['ms_per_step_min'])" || exit 1
+done
+for v in 0 1; do
+  echo "b64 GPT_PRUNE_LAST=$v"; GPT_PRUNE_LAST=$v timeout -k 10 200 python bench.py --batch 64 --steps 400 --warmup 40 --no-train --no-extra --no-cpu-baseline --no-roofline --repeats 3 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['spread']['ms_per_step_min'])" || exit 1
+  echo "cifar GPT_PRUNE_LAST=$v"; GPT_PRUNE_LAST=$v timeout -k 10 200 python bench.py --case cifar --batch 1280 --steps 40 --warmup 5 --no-train --no-extra --no-cpu-baseline --no-roofline --repeats 2 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['spread']['ms_per_step_min'])" || exit 1
+done
