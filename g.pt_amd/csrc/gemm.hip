@@ -629,14 +629,15 @@ double cost_rows224(const GemmArgs<T>& g) {
 // (B = 64 sampling, fc1: M = 1664, N = 6144 -> 216 tiles of 3/4 the main-loop work instead of 192 of 7/8)
 template <typename T>
 double cost_rows192(const GemmArgs<T>& g) {
-  static const bool enabled = [] {
-    const char* e = getenv("GPT_GEMM_192");    // 0 disables (A/B measurements)
-    return !e || atoi(e) != 0;
+  static const int max_rounds = [] {
+    const char* e = getenv("GPT_GEMM_192");    // 0 disables, n = at most n rounds (A/B measurements)
+    return e ? atoi(e) : 1;
   }();
-  if (!enabled || sizeof(T) != 2) return 1e30;
+  if (max_rounds <= 0 || sizeof(T) != 2) return 1e30;
   const int tiles = ((g.M + 191) / 192) * ((g.N + 255) / 256);
-  if (tiles > n_cus()) return 1e30;
-  return 0.80 + 0.02;
+  const int rounds = (tiles + n_cus() - 1) / n_cus();
+  if (rounds > max_rounds) return 1e30;
+  return rounds * 0.80 + 0.02;
 }
 
 template <typename T>
@@ -753,9 +754,12 @@ static int pick_spans_ln(int M, int N, int K, int* rt) {
     }
   }
   if (sp < 2) {
-    const int tiles = tiles128 * 2 <= n_cus() ? tiles128 : tiles256;
-    *rt = tiles == tiles128 ? 4 : 8;
-    sp = n_cus() / tiles;
+    // r03: where half-height tiles already give more than half the CUs a tile (M = 3328 / 3520, N = 1536: 156 / 168 of them) the
+    // single pass on gemm128.hip + the LayerNorm kernel beats three spans of full-height tiles + the fused pass: 36 against 45 - 47 us
+    // (tools/resadd_ln_bench.py; M = 1664: 28 either way, so the span route stays there)
+    if (tiles128 * 2 > n_cus()) return 1;
+    *rt = 4;
+    sp = n_cus() / tiles128;
     if (sp > nk / 8) sp = nk / 8;
   }
   const size_t slab = (size_t)M * N * sizeof(float);
