@@ -753,6 +753,10 @@ static int pick_spans_ln(int M, int N, int K, int* rt) {
       sp = sp128;
     }
   }
+  // r03: very few rows (the pruned last Block at B = 64: M = 704, K = 6144 -> 18 tiles x 6 spans = 108 workgroups): the same span
+  // count on half-height tiles fills twice the CUs at the same partial-tile traffic
+  static const bool fill128 = [] { const char* e = getenv("GPT_LN_FILL128"); return !e || atoi(e) != 0; }();   // 0: A/B
+  if (fill128 && *rt == 8 && sp >= 2 && tiles256 * sp * 2 <= n_cus() && tiles128 * sp <= n_cus()) *rt = 4;
   if (sp < 2) {
     // r03: where half-height tiles already give more than half the CUs a tile (M = 3328 / 3520, N = 1536: 156 / 168 of them) the
     // single pass on gemm128.hip + the LayerNorm kernel beats three spans of full-height tiles + the fused pass: 36 against 45 - 47 us
