@@ -99,6 +99,9 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 // tile to that device scalar (gpt_backward_t.wgrad_sumsq)
 int gpt_tn_grouped_sumsq(int n, const void* const* P, const int64_t* ldp, const void* const* Q, const int64_t* ldq, float* const* C,
                          const int64_t* ldc, const int* I, const int* J, int R, int accumulate, float* sumsq, void* stream);
+// ... and with one contraction length per problem (store mode, or accumulate mode where all lengths are equal)
+int gpt_tn_grouped_sumsq_r(int n, const void* const* P, const int64_t* ldp, const void* const* Q, const int64_t* ldq, float* const* C,
+                           const int64_t* ldc, const int* I, const int* J, const int* R, int accumulate, float* sumsq, void* stream);
 
 // gpt_randn (stream (seed, sid) over a [B, D] buffer) + gpt_posterior_step with every row at timestep t, in one kernel (the DDPM
 // sampling loop's step; bit-identical to the two calls)
@@ -126,6 +129,8 @@ int gpt_ln_partials_reduce(const LnPartCalls& calls, int d, void* stream);
 // residual rows (the pruned last Block of an inference forward, model.cpp)
 int gpt_attention_rows(int dtype, const void* qkv, void* y, int B, int T, int t_out, int n_head, int hd, void* stream);
 int gpt_gather_token_rows(const float* src, float* dst, int B, int T, int t_out, int d, void* stream);
+// the inverse: dst[b * T + r, :] = r < t_out ? src[b * t_out + r, :] : 0, rows of d elements of elem_bytes (2 or 4) each
+int gpt_scatter_token_rows(const void* src, void* dst, int B, int T, int t_out, int d, int elem_bytes, void* stream);
 
 // gpt_small_gemm_batched with one more (internal) argument: bf16_mma != 0 rounds both operands to bf16 and multiplies them on the
 // bf16 matrix pipe (the denoiser backward in bf16 compute mode); 0 = the exact-fp32 pipe

@@ -327,16 +327,25 @@ extern "C" int gpt_gemm_tn_grouped(int n, const void* const* P, const int64_t* l
 
 int gpt_tn_grouped_sumsq(int n, const void* const* P, const int64_t* ldp, const void* const* Q, const int64_t* ldq, float* const* C,
                          const int64_t* ldc, const int* I, const int* J, int R, int accumulate, float* sumsq, void* stream) {
+  int Rs[gemmk::TN_MAX_GROUP];
+  for (int p = 0; p < gemmk::TN_MAX_GROUP; ++p) Rs[p] = R;
+  return gpt_tn_grouped_sumsq_r(n, P, ldp, Q, ldq, C, ldc, I, J, Rs, accumulate, sumsq, stream);
+}
+
+int gpt_tn_grouped_sumsq_r(int n, const void* const* P, const int64_t* ldp, const void* const* Q, const int64_t* ldq, float* const* C,
+                           const int64_t* ldc, const int* I, const int* J, const int* R, int accumulate, float* sumsq, void* stream) {
   using namespace gemmk;
   GPT_REQUIRE(!sumsq || !accumulate, "gpt_gemm_tn_grouped: the sum of squares exists in store mode only");
-  GPT_REQUIRE(n >= 1 && n <= TN_MAX_GROUP && P && ldp && Q && ldq && C && ldc && I && J, "gpt_gemm_tn_grouped: need 1..%d problems", TN_MAX_GROUP);
+  GPT_REQUIRE(n >= 1 && n <= TN_MAX_GROUP && P && ldp && Q && ldq && C && ldc && I && J && R, "gpt_gemm_tn_grouped: need 1..%d problems", TN_MAX_GROUP);
   TnGroup grp;
   grp.n = n;
   grp.sumsq = sumsq;
   for (int p = 0; p < n; ++p) {
-    const int rc = tn_check(P[p], ldp[p], Q[p], ldq[p], C[p], ldc[p], I[p], J[p], R);
+    const int rc = tn_check(P[p], ldp[p], Q[p], ldq[p], C[p], ldc[p], I[p], J[p], R[p]);
     if (rc != 0) return rc;
-    grp.g[p] = GemmArgs<bf16_t>{(const bf16_t*)P[p], (const bf16_t*)Q[p], nullptr, C[p], nullptr, ldp[p], ldq[p], ldc[p], 0, I[p], J[p], R};
+    grp.g[p] = GemmArgs<bf16_t>{(const bf16_t*)P[p], (const bf16_t*)Q[p], nullptr, C[p], nullptr, ldp[p], ldq[p], ldc[p], 0, I[p], J[p], R[p]};
   }
+  // (an accumulating launch may cut the contractions into spans: ONE span count for the group, chosen for the first problem; every
+  // problem cuts its own length by it and the kernel drops the spans a shorter problem leaves empty)
   return accumulate ? launch_tn<GPT_EPI_ACCUM_F32>(grp, (hipStream_t)stream) : launch_tn<GPT_EPI_STORE_F32>(grp, (hipStream_t)stream);
 }

@@ -39,6 +39,20 @@ static int validate(const gpt_model_t* m, const gpt_workspace_t* ws, int B, cons
 
 // enc_cached != 0: the encoder output of the tokens that do not depend on x or t (x_prev, the loss scalars) is already in
 // ws->enc from an earlier call with the same x_prev / losses (the sampling loops): only the other tokens are encoded.
+// Training (kept activations): the last Block behind its attention, the final LayerNorm and the decoder touch only the rows of the
+// tokens the decoder reads (the loss does not depend on the others: their rows of the last Block's projection / MLP are dead
+// work in the forward and all-zero gradients in the backward).  Forward and backward drivers must agree, so both ask this:
+// bf16 on the grouped TN weight-gradient route, and both row counts multiples of the TN kernel's 64-row K-tiles.
+static bool prune_last_train(const gpt_model_t* m, int B) {
+  static const bool on = [] {
+    const char* e = getenv("GPT_PRUNE_LAST_TRAIN");   // 0: all rows (cross-check, A/B)
+    const char* tn = getenv("GPT_WGRAD_TN");
+    return (!e || atoi(e) != 0) && (!tn || atoi(tn) != 0);
+  }();
+  const int To = m->n_out_tok, T = m->T;
+  return on && m->dtype == GPT_BF16 && m->n_layer > 0 && To < T && (B * T) % 64 == 0 && (B * To) % 64 == 0 && m->d % 256 == 0;
+}
+
 static int denoiser_forward(const gpt_model_t* m, const gpt_workspace_t* ws, const float* x, const int64_t* t,
                             const void* loss_target, const void* loss_prev, int loss_is_f64, const float* x_prev, float* out,
                             int B, int enc_cached, void* stream) {
@@ -106,6 +120,19 @@ static int denoiser_forward(const gpt_model_t* m, const gpt_workspace_t* ws, con
     CHECK(wait_ready(ly.ready, stream));
     CHECK(gpt_gemm_nt(dt, h1, d, ly.wqkv, d, ly.bqkv, qkv, 3 * d, nullptr, 0, M, 3 * d, d, GPT_EPI_STORE, stream));
     const bool last = l + 1 == L;
+    if (last && keep && prune_last_train(m, B)) {
+      const int To = m->n_out_tok, Mc = B * To;
+      void* pre = lay(ws->pre, l, 4 * (size_t)d);
+      CHECK(gpt_attention_rows(dt, qkv, att, B, T, To, m->n_head, d / m->n_head, stream));
+      CHECK(gpt_gather_token_rows(xin, xmid, B, T, To, d, stream));                 // compact residual rows: [B * To, d]
+      CHECK(gpt_gemm_resadd_layernorm(dt, att, d, ly.wproj, d, ly.bproj, xmid, d, xmid, d, ly.ln2_w, ly.ln2_b, h2, stat(2 + 2 * l, 0),
+                                      stat(2 + 2 * l, 1), Mc, d, d, 1e-5f, stream));
+      CHECK(gpt_gemm_nt(dt, h2, d, ly.w1, d, ly.b1, act, 4 * d, pre, 4 * d, Mc, 4 * d, d, GPT_EPI_GELU_AUX, stream));
+      CHECK(gpt_gemm_resadd_layernorm(dt, act, 4 * d, ly.w2, 4 * d, ly.b2, xmid, d, xout, d, m->ln_f_w, m->ln_f_b, ws->hf, stat(2 * L + 1, 0),
+                                      stat(2 * L + 1, 1), Mc, d, 4 * d, 1e-5f, stream));
+      CHECK(wait_ready(m->dec_ready, stream));
+      return gpt_decode_tokens(dt, To, ws->hf, To, m->dec_w, m->dec_n, m->dec_off, x_prev, out, B, d, m->D, stream);
+    }
     if (last && prune) {
       // The decoder reads the first n_out_tok tokens only (transformer.py:237-240), and behind the last Block's attention rows
       // do not mix any more: its projection, LayerNorms and MLP run on those rows alone, compacted to [B * To, d] (the attention
@@ -263,13 +290,14 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
     return !e || atoi(e) != 0;
   }();
   auto ln_bwd = [&](const void* dy, int dy_dt, const float* xin, const float* mean, const float* rstd, const float* gamma,
-                    const float* resid, float* gout, void* gout_t, int gout_t_dt, float* dgamma, float* dbeta, float* gcol) -> int {
+                    const float* resid, float* gout, void* gout_t, int gout_t_dt, float* dgamma, float* dbeta, float* gcol,
+                    int rows) -> int {
     float* part = nullptr;
     if (ln_part_on && bw->ln_partials && ln_calls.n < GPT_LN_PART_MAX_CALLS &&
         (ln_calls.n + 1) * ln_slot * (int64_t)sizeof(float) <= bw->ln_partials_bytes)
       part = bw->ln_partials + ln_calls.n * ln_slot;
     int nb = 0;
-    CHECK(gpt_layernorm_bwd_part(dy, dy_dt, xin, mean, rstd, gamma, resid, gout, gout_t, gout_t_dt, dgamma, dbeta, gcol, part, &nb, M, d,
+    CHECK(gpt_layernorm_bwd_part(dy, dy_dt, xin, mean, rstd, gamma, resid, gout, gout_t, gout_t_dt, dgamma, dbeta, gcol, part, &nb, rows, d,
                                  stream));
     if (part) {
       auto& c = ln_calls.c[ln_calls.n++];
@@ -287,8 +315,11 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
   };
 
   // stage 0 - decoder: d_tok[b, j, :] = d_out[b, off_j..] . W_j (zero for the tokens that are not decoded);  dW_j += d_out_j^T . hf_j
+  // pruned last Block (prune_last_train): everything up to that Block's attention backward runs on the compact rows [B * To, d]
+  const bool pruned = prune_last_train(m, B);
+  const int To = m->n_out_tok, Mc = pruned ? B * To : M, Tc = pruned ? To : T;
   if (stage_begin == 0) {
-  if (hipMemsetAsync(bw->d_tok, 0, (size_t)M * d * sizeof(float), hs) != hipSuccess) { gpt_set_error("memset failed"); return -1; }
+  if (hipMemsetAsync(bw->d_tok, 0, (size_t)Mc * d * sizeof(float), hs) != hipSuccess) { gpt_set_error("memset failed"); return -1; }
   {
     const void *pa[GPT_MAX_TOKENS], *pw[GPT_MAX_TOKENS], *ph[GPT_MAX_TOKENS];
     float *pt[GPT_MAX_TOKENS], *pg[GPT_MAX_TOKENS];
@@ -299,18 +330,18 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
       ph[j] = (const char*)ws->hf + (size_t)j * d * es;
       pt[j] = bw->d_tok + (size_t)j * d;
       pg[j] = bw->g_dec_w[j];
-      vB[j] = B; vd[j] = d; vn[j] = m->dec_n[j]; vTd[j] = T * d;
+      vB[j] = B; vd[j] = d; vn[j] = m->dec_n[j]; vTd[j] = Tc * d;
     }
     // d_tok[b, j, :] = d_out[b, off_j ..] . W_j            (M = B, N = d, K = n_j)
     CHECK(gpt_small_gemm_batched_mode(m->n_out_tok, GPT_F32, pa, m->D, 1, dt, pw, d, 1, pt, vTd, vB, vd, vn, 0, mma16, stream));
     // dW_j[n, :] += sum_b d_out[b, off_j + n] hf[b, j, :]   (M = n_j, N = d, K = B)
-    CHECK(gpt_small_gemm_batched_mode(m->n_out_tok, GPT_F32, pa, 1, m->D, dt, ph, (int64_t)T * d, 1, pg, vd, vn, vd, vB, 1, mma16, stream));
+    CHECK(gpt_small_gemm_batched_mode(m->n_out_tok, GPT_F32, pa, 1, m->D, dt, ph, (int64_t)Tc * d, 1, pg, vd, vn, vd, vB, 1, mma16, stream));
   }
   // bw->g / bw->gt = gradient of the residual stream behind the last Block = dY of its mlp.2: the bias gradient g_b2 is its column sum,
   // taken by the LayerNorm backward that produces it (and so for every Block below: ln1's backward of Block l + 1 feeds Block l's mlp.2,
   // ln2's backward feeds the attention projection of its own Block)
   CHECK(ln_bwd(bw->d_tok, GPT_F32, xbuf(2 * L), stat(2 * L + 1, 0), stat(2 * L + 1, 1), m->ln_f_w, nullptr, bw->g, bw->gt,
-               dt, bw->g_ln_f_w, bw->g_ln_f_b, fuse_col && L > 0 ? bw->layers[L - 1].g_b2 : nullptr));
+               dt, bw->g_ln_f_w, bw->g_ln_f_b, fuse_col && L > 0 ? bw->layers[L - 1].g_b2 : nullptr, Mc));
   }
 
   // stages 1 .. L - the blocks, last to first (stage s = layer L - s)
@@ -330,14 +361,14 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
   struct {
     const void *P[16], *Q[16];
     float* C[16];
-    int I[16], J[16];
+    int I[16], J[16], R[16];
     int64_t ldp[16], ldq[16], ldc[16];
     int n = 0;
   } pend;
   auto flush = [&]() -> int {
     if (pend.n == 0) return 0;
-    const int rc = gpt_tn_grouped_sumsq(pend.n, pend.P, pend.ldp, pend.Q, pend.ldq, pend.C, pend.ldc, pend.I, pend.J, M,
-                                        bw->wgrad_overwrite ? 0 : 1, bw->wgrad_sumsq, stream);
+    const int rc = gpt_tn_grouped_sumsq_r(pend.n, pend.P, pend.ldp, pend.Q, pend.ldq, pend.C, pend.ldc, pend.I, pend.J, pend.R,
+                                          bw->wgrad_overwrite ? 0 : 1, bw->wgrad_sumsq, stream);
     pend.n = 0;
     return rc;
   };
@@ -357,23 +388,36 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
     const void* act = lay(ws->act, l, 4 * (size_t)d);
     void* pre = lay(ws->pre, l, 4 * (size_t)d);
     void* gt2 = grouped ? slot(bw->tA, sl, d) : bw->gt;  // dY of the attention projection ([4d, Mp] holds four [M, d] slots)
+    // rows of this Block's projection / MLP half: the decoded tokens' compact rows in the pruned last Block, else all
+    const bool cmp = pruned && l == L - 1;
+    const int Ml = cmp ? Mc : M;
     // mlp.2
-    if (!fuse_col) CHECK(gpt_colsum(dt, gt_l, d, gl.g_b2, M, d, stream));
+    if (!fuse_col) CHECK(gpt_colsum(dt, gt_l, d, gl.g_b2, Ml, d, stream));
     if (!grouped) CHECK(wgrad(gt_l, d, act, 4 * d, gl.g_w2));
     // ... and mlp.0's bias gradient = the column sums of that output, taken in the same epilogue
-    CHECK(gpt_gemm_nt_colsum(dt, gt_l, d, gl.w2_t, d, nullptr, d_act_l, 4 * d, pre, 4 * d, M, 4 * d, d, GPT_EPI_DGELU,
+    CHECK(gpt_gemm_nt_colsum(dt, gt_l, d, gl.w2_t, d, nullptr, d_act_l, 4 * d, pre, 4 * d, Ml, 4 * d, d, GPT_EPI_DGELU,
                              fuse_b1 ? gl.g_b1 : nullptr, stream));
     // mlp.0
-    if (!fuse_b1) CHECK(gpt_colsum(dt, d_act_l, 4 * d, gl.g_b1, M, 4 * d, stream));
+    if (!fuse_b1) CHECK(gpt_colsum(dt, d_act_l, 4 * d, gl.g_b1, Ml, 4 * d, stream));
     if (!grouped) CHECK(wgrad(d_act_l, 4 * d, h2, d, gl.g_w1));
-    CHECK(gpt_gemm_nt(dt, d_act_l, 4 * d, gl.w1_t, 4 * d, nullptr, bw->d_h, d, nullptr, 0, M, d, 4 * d, GPT_EPI_STORE, stream));
-    CHECK(ln_bwd(bw->d_h, dt, xbuf(2 * l + 1), stat(2 + 2 * l, 0), stat(2 + 2 * l, 1), ly.ln2_w, bw->g, bw->g, gt2, dt,
-                 gl.g_ln2_w, gl.g_ln2_b, fuse_col ? gl.g_bproj : nullptr));
+    CHECK(gpt_gemm_nt(dt, d_act_l, 4 * d, gl.w1_t, 4 * d, nullptr, bw->d_h, d, nullptr, 0, Ml, d, 4 * d, GPT_EPI_STORE, stream));
+    // (compact rows: the residual gradient leaves this LayerNorm backward in bw->d_tok, free between stage 0 and stage L + 1, and
+    // is scattered back to all rows below)
+    CHECK(ln_bwd(bw->d_h, dt, xbuf(2 * l + 1), stat(2 + 2 * l, 0), stat(2 + 2 * l, 1), ly.ln2_w, bw->g, cmp ? bw->d_tok : bw->g, gt2, dt,
+                 gl.g_ln2_w, gl.g_ln2_b, fuse_col ? gl.g_bproj : nullptr, Ml));
     // attention output projection
-    if (!fuse_col) CHECK(gpt_colsum(dt, gt2, d, gl.g_bproj, M, d, stream));
+    if (!fuse_col) CHECK(gpt_colsum(dt, gt2, d, gl.g_bproj, Ml, d, stream));
     if (!grouped) CHECK(wgrad(gt2, d, att, d, gl.g_wproj));
-    CHECK(gpt_gemm_nt(dt, gt2, d, gl.wproj_t, d, nullptr, bw->d_h, d, nullptr, 0, M, d, d, GPT_EPI_STORE, stream));
-    CHECK(gpt_attention_bwd(dt, qkv, bw->d_h, d_qkv_l, B, T, m->n_head, d / m->n_head, stream));
+    CHECK(gpt_gemm_nt(dt, gt2, d, gl.wproj_t, d, nullptr, bw->d_h, d, nullptr, 0, Ml, d, d, GPT_EPI_STORE, stream));
+    const void* d_att = bw->d_h;
+    if (cmp) {
+      // back to all rows: the attention mixes tokens.  Gradient of the attention output and of the residual stream are zero in
+      // the rows of the tokens the decoder does not read (bw->tB: the NT fallback's transpose scratch, unused on this route)
+      CHECK(gpt_scatter_token_rows(bw->d_h, bw->tB, B, T, To, d, (int)es, stream));
+      CHECK(gpt_scatter_token_rows(bw->d_tok, bw->g, B, T, To, d, 4, stream));
+      d_att = bw->tB;
+    }
+    CHECK(gpt_attention_bwd(dt, qkv, d_att, d_qkv_l, B, T, m->n_head, d / m->n_head, stream));
     // query | key | value
     CHECK(gpt_colsum(dt, d_qkv_l, 3 * d, gl.g_bqkv, M, 3 * d, stream));
     if (grouped) {
@@ -382,9 +426,10 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
       const void* Q[4] = {act, h2, h1, att};
       float* Cg[4] = {gl.g_w2, gl.g_w1, gl.g_wqkv, gl.g_wproj};
       const int I[4] = {d, 4 * d, 3 * d, d}, J[4] = {4 * d, d, d, d};
+      const int Rk[4] = {Ml, Ml, M, Ml};                      // contraction lengths: only q|k|v sees all rows in the pruned Block
       for (int k = 0; k < 4; ++k) {
         const int n = pend.n++;
-        pend.P[n] = P[k]; pend.Q[n] = Q[k]; pend.C[n] = Cg[k]; pend.I[n] = I[k]; pend.J[n] = J[k];
+        pend.P[n] = P[k]; pend.Q[n] = Q[k]; pend.C[n] = Cg[k]; pend.I[n] = I[k]; pend.J[n] = J[k]; pend.R[n] = Rk[k];
         pend.ldp[n] = I[k]; pend.ldq[n] = J[k]; pend.ldc[n] = J[k];
       }
       if (pend.n == 4 * G) CHECK(flush());
@@ -393,14 +438,14 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
     }
     CHECK(gpt_gemm_nt(dt, d_qkv_l, 3 * d, gl.wqkv_t, 3 * d, nullptr, bw->d_h, d, nullptr, 0, M, d, 3 * d, GPT_EPI_STORE, stream));
     CHECK(ln_bwd(bw->d_h, dt, xbuf(2 * l), stat(1 + 2 * l, 0), stat(1 + 2 * l, 1), ly.ln1_w, bw->g, bw->g, gt_next, dt,
-                 gl.g_ln1_w, gl.g_ln1_b, fuse_col && l > 0 ? bw->layers[l - 1].g_b2 : nullptr));
+                 gl.g_ln1_w, gl.g_ln1_b, fuse_col && l > 0 ? bw->layers[l - 1].g_b2 : nullptr, M));
   }
   CHECK(flush());                                        // what this call collected (gradients are complete when it returns)
   if (stage_end < L + 2) return gpt_ln_partials_reduce(ln_calls, d, stream);
   // stage L + 1 - position embedding: sum over the batch of the gradient of x0 = ln_in(enc) + pos_emb
   CHECK(gpt_colsum(GPT_F32, bw->g, (int64_t)T * d, bw->g_pos_emb, B, T * d, stream));
   CHECK(ln_bwd(bw->g, GPT_F32, ws->enc, stat(0, 0), stat(0, 1), m->ln_in_w, nullptr, bw->d_tok, nullptr, GPT_F32,
-               bw->g_ln_in_w, bw->g_ln_in_b, nullptr));
+               bw->g_ln_in_w, bw->g_ln_in_b, nullptr, M));
   CHECK(gpt_ln_partials_reduce(ln_calls, d, stream));
   {
     // dW_i[:, k] += sum_b d_tok[b, i, :] src_i[b, k]        (M = d, N = k_i, K = B); sources grouped by their row stride

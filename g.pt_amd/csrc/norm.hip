@@ -217,3 +217,29 @@ int gpt_gather_token_rows(const float* src, float* dst, int B, int T, int t_out,
                      t_out, d / 4, n4);
   return gpt_launch_status("gpt_gather_token_rows");
 }
+
+
+namespace {
+__global__ __launch_bounds__(256) void scatter_token_rows_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int T, int t_out,
+                                                                 int v_per_row, int64_t n_vec) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / v_per_row;
+    const int c = (int)(i - row * v_per_row);
+    const int64_t b = row / T;
+    const int r = (int)(row - b * T);
+    dst[i] = r < t_out ? src[(b * t_out + r) * v_per_row + c] : make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+}  // namespace
+
+int gpt_scatter_token_rows(const void* src, void* dst, int B, int T, int t_out, int d, int elem_bytes, void* stream) {
+  GPT_REQUIRE(src && dst && src != dst && B > 0 && t_out > 0 && t_out <= T && d > 0 && (elem_bytes == 2 || elem_bytes == 4) &&
+                  (d * elem_bytes) % 16 == 0,
+              "gpt_scatter_token_rows: bad arguments");
+  GPT_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "gpt_scatter_token_rows: buffers must be 16-byte aligned");
+  const int vpr = d * elem_bytes / 16;
+  const int64_t n_vec = (int64_t)B * T * vpr, blocks = (n_vec + 255) / 256;
+  hipLaunchKernelGGL(scatter_token_rows_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)src, (uint4*)dst, T, t_out, vpr, n_vec);
+  return gpt_launch_status("gpt_scatter_token_rows");
+}

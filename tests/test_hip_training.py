@@ -824,6 +824,62 @@ torch.save({k: p.grad.cpu() for k, p in m.named_parameters()}, sys.argv[1])
         assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-12) + 1e-9, k
 
 
+def test_pruned_last_block_training_equals_all_rows():
+    """prune_last_train (csrc/model.cpp): the last Block behind its attention, ln_f and the decoder on the decoded tokens' rows alone
+    (forward with kept activations AND backward: compact dgrad / LayerNorm backward, scatter before the attention backward, the
+    grouped weight-gradient launch with one contraction length per problem) against the same step on all rows
+    (GPT_PRUNE_LAST_TRAIN=0, a process of its own: the switch is read once): loss and every gradient, store mode and accumulate mode."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from tests.test_hip_parity import build, DEV
+from tests.cases import make_inputs
+import gpt_amd
+from gpt_amd.trainstep import TrainStep
+out = {}
+for tag, B in (("store", 64), ("accum", 128)):
+    m, plan, sd = build("cifar_small", "bf16", seed=6)
+    m.train()
+    diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
+    _, _, lt, lp, xp = (v.to(DEV) for v in make_inputs("cifar_small", B=B, seed=7))
+    g = torch.Generator().manual_seed(8)
+    x1 = xp + 0.1 * torch.randn(xp.shape, generator=g).to(DEV)
+    t = torch.randint(0, 1000, (B,), generator=g).to(DEV)
+    noise = torch.randn(xp.shape, generator=g).to(DEV)
+    if tag == "store":
+        ts = TrainStep(m, diff, lr=1e-3, wd=0.1, grad_clip=0.75, use_ema=False)
+        out[tag + ".mse"] = ts.loss_and_grads(xp, x1, lp, lt, t, noise=noise).cpu()
+        assert ts._overwrote
+    else:                                  # the autograd bridge accumulates (float atomics over row spans)
+        terms = diff.training_losses(m, x1, t, model_kwargs=dict(loss_target=lt, loss_prev=lp, x_prev=xp), noise=noise)
+        terms["loss"].mean().backward()
+        out[tag + ".mse"] = terms["mse"].detach().cpu()
+    for k, p in m.named_parameters():
+        out[tag + "." + k] = p.grad.detach().cpu().clone()
+torch.save(out, sys.argv[1])
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for flag in ("1", "0"):
+            path = os.path.join(td, f"g{flag}.pt")
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, GPT_PRUNE_LAST_TRAIN=flag), timeout=250)
+            outs.append(torch.load(path, weights_only=True))
+    for k in outs[0]:
+        a, b = outs[0][k].double(), outs[1][k].double()
+        if k.endswith(".mse"):
+            assert float(((a - b).abs() / b.abs()).max()) < 5e-3, k
+            continue
+        if k.endswith("attn.key.bias"):
+            continue
+        err = float((a - b).abs().max() / (b.abs().max() + 1e-30))
+        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+        assert err < 1.5e-2 and cos > 0.9999, (k, err, cos)
+
+
 def _native_dp_rank(out_path):
     """gpt_dp_* (include/gpt_hip.h) with the one rank a one-GPU box allows: every collective really runs on RCCL; with one rank
     each is the identity, so values are checked exactly."""
