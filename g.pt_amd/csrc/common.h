@@ -106,7 +106,8 @@ int gpt_tn_grouped_sumsq_r(int n, const void* const* P, const int64_t* ldp, cons
 // gpt_randn (stream (seed, sid) over a [B, D] buffer) + gpt_posterior_step with every row at timestep t, in one kernel (the DDPM
 // sampling loop's step; bit-identical to the two calls)
 int gpt_posterior_step_philox(const float* model_out, const float* x_t, int64_t t, const float* coef, int predict_xstart, int use_clamp,
-                              float lo, float hi, uint64_t seed, uint64_t sid, float* x_out, int B, int D, void* stream);
+                              float lo, float hi, uint64_t seed, uint64_t sid, float* x_out, int B, int D, int64_t* t_next,
+                              int64_t t_next_value, void* stream);   // t_next != NULL: also t_next[0..B) = t_next_value
 
 // gpt_layernorm_bwd_colsum with a partials buffer: part != NULL ([<= 256][3][d] floats) receives every workgroup's dgamma / dbeta /
 // gcol sums by plain stores instead of float atomics into the outputs, *n_blocks the number of rows written; the caller adds them up

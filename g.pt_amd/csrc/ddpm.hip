@@ -132,8 +132,11 @@ template <int V>
 __global__ __launch_bounds__(256) void posterior_philox_kernel(const float* __restrict__ mo, const float* __restrict__ xt, int64_t tb,
                                                                const float* __restrict__ coef, int predict_xstart, int use_clamp,
                                                                float lo, float hi, uint64_t seed, uint64_t sid,
-                                                               float* __restrict__ xout, int B, int DV) {
+                                                               float* __restrict__ xout, int B, int DV, int64_t* __restrict__ t_next,
+                                                               int64_t t_next_value) {
   const int b = blockIdx.y;
+  // the NEXT step's model timestep for this row (the loop's forward reads it from a [B] array): saves the loop a fill launch
+  if (t_next && blockIdx.x == 0 && threadIdx.x == 0) t_next[b] = t_next_value;
   PostScal p;
   p.c1 = coef[tb * NC + GPT_C_POST1];
   p.c2 = coef[tb * NC + GPT_C_POST2];
@@ -372,7 +375,8 @@ extern "C" int gpt_posterior_step(const float* model_out, const float* x_t, cons
 }
 
 int gpt_posterior_step_philox(const float* model_out, const float* x_t, int64_t t, const float* coef, int predict_xstart, int use_clamp,
-                              float lo, float hi, uint64_t seed, uint64_t sid, float* x_out, int B, int D, void* stream) {
+                              float lo, float hi, uint64_t seed, uint64_t sid, float* x_out, int B, int D, int64_t* t_next,
+                              int64_t t_next_value, void* stream) {
   GPT_REQUIRE(model_out && x_t && coef && x_out && t >= 0, "gpt_sample_loop: posterior step: null operand");
   GPT_REQUIRE(B > 0 && D > 0, "gpt_sample_loop: posterior step: empty problem (B=%d D=%d)", B, D);
   const int V = vec_width(D, model_out, x_t, x_out, nullptr, nullptr);
@@ -381,7 +385,7 @@ int gpt_posterior_step_philox(const float* model_out, const float* x_t, int64_t 
   hipStream_t s = (hipStream_t)stream;
 #define POSTP(VV)                                                                                                          \
   hipLaunchKernelGGL(posterior_philox_kernel<VV>, grid, dim3(256), 0, s, model_out, x_t, t, coef, predict_xstart, use_clamp, lo, hi, \
-                     seed, sid, x_out, B, D / VV)
+                     seed, sid, x_out, B, D / VV, t_next, t_next_value)
   if (V == 4) POSTP(4);
   else if (V == 2) POSTP(2);
   else POSTP(1);

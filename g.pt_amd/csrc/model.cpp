@@ -198,13 +198,16 @@ static int sample_loop(const char* who, int ddim, float eta, const float* alphas
     const char* e = getenv("GPT_POST_PHILOX");   // 0: gpt_randn + gpt_posterior_step as separate launches (cross-check, A/B)
     return !e || atoi(e) != 0;
   }();
+  const bool fused_post = !ddim && !noise && fuse_noise;
   for (int i = first_step; i >= last_step; --i) {
-    CHECK(gpt_fill_i64(t_model, B, host_timestep_map[i], stream));
+    // (the fused posterior kernel of step i + 1 has written this step's model timesteps already)
+    if (!fused_post || i == first_step) CHECK(gpt_fill_i64(t_model, B, host_timestep_map[i], stream));
     // x_prev and the losses are the loop's constants: their tokens are encoded in the first step only
     CHECK(denoiser_forward(m, ws, x, t_model, loss_target, loss_prev, loss_is_f64, x_prev, model_out, B, i != first_step, stream));
-    if (!ddim && !noise && fuse_noise) {
+    if (fused_post) {
       // DDPM with in-kernel noise: Philox + posterior update in one kernel, the timestep as a scalar
-      CHECK(gpt_posterior_step_philox(model_out, x, i, coef, predict_xstart, use_clamp, lo, hi, seed, (uint64_t)i, x, B, m->D, stream));
+      CHECK(gpt_posterior_step_philox(model_out, x, i, coef, predict_xstart, use_clamp, lo, hi, seed, (uint64_t)i, x, B, m->D,
+                                      i > last_step ? t_model : nullptr, i > last_step ? host_timestep_map[i - 1] : 0, stream));
       continue;
     }
     CHECK(gpt_fill_i64(t_index, B, i, stream));
