@@ -1,3 +1,10 @@
+# One MI355X session: the whole GPU suite, smoke() and the default bench line (run through gpurun from the repo root).
 set -o pipefail
-timeout -k 10 600 python -u -m pytest -x -q -m gpu --timeout 300 --timeout-method thread tests/test_hip_parity.py tests/test_hip_chains.py -k "sampl or loop or ddim or chain or seeded" 2>&1 | grep -E "^E  |passed|failed|Error" | head -20 || exit 1
-for i in 1 2; do timeout -k 10 200 python bench.py --batch 64 --steps 400 --warmup 40 --no-train --no-extra --no-cpu-baseline --no-roofline --repeats 3 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('b64', d['ms_per_step'], d['spread']['ms_per_step_min'])" || exit 1; done
+mkdir -p gpurun_out
+timeout -k 10 1500 python -u -m pytest tests -x -q -m gpu --timeout 400 --timeout-method thread > gpurun_out/r3_gpu_all.log 2>&1; rc=$?; tail -3 gpurun_out/r3_gpu_all.log | cut -c1-300
+if grep -q "HSA_STATUS_ERROR\|Memory access fault" gpurun_out/r3_gpu_all.log; then echo FAULT; exit 1; fi
+[ $rc -eq 0 ] || { grep -E "^E |Error" gpurun_out/r3_gpu_all.log | head -20; exit $rc; }
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1 || { tail -5 gpurun_out/smoke.log; exit 1; }
+tail -1 gpurun_out/smoke.log
+timeout -k 10 500 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err || { tail -20 gpurun_out/bench.err; exit 1; }
+cut -c1-600 gpurun_out/bench.json
