@@ -24,6 +24,11 @@ constexpr int RB = 128;                    // bytes of K per LDS row (64 bf16)
 constexpr int A_ROWS = 128, W_ROWS = 256;
 constexpr int STAGE = (A_ROWS + W_ROWS) * RB;   // 48 KiB
 constexpr int LDS128_BYTES = 3 * STAGE;         // 144 KiB
+// diagnostic builds only (tools/gemm_ablate.sh with FILE=gemm128; results are garbage): bit 0 = no DMA in the steady loop, bit 1 = no
+// fragment reads, bit 2 = no barriers in the loop, bit 3 = no MFMAs
+#ifndef GPT_ABL128
+#define GPT_ABL128 0
+#endif
 
 __device__ __forceinline__ u32x4 frag128(const char* base, int row, int lc) {
   return *reinterpret_cast<const u32x4*>(base + row * RB + ((lc ^ ((row >> 1) & 7)) << 4));
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(512, 2) void gemm128_kernel(GemmArgs<bf16_t> g) {
 #define SEG_BARRIER()                        \
   do {                                       \
     __builtin_amdgcn_sched_barrier(0);       \
-    __builtin_amdgcn_s_barrier();            \
+    if (!(GPT_ABL128 & 4)) __builtin_amdgcn_s_barrier(); \
     __builtin_amdgcn_sched_barrier(0);       \
   } while (0)
 
@@ -107,6 +112,12 @@ __global__ __launch_bounds__(512, 2) void gemm128_kernel(GemmArgs<bf16_t> g) {
     const char* sa = smem + s0;
     const char* sw = sa + A_ROWS * RB;
     u32x4 a[4][2], b[4][2];
+    if (GPT_ABL128 & 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) { asm volatile("" : "=v"(a[j][kk])); asm volatile("" : "=v"(b[j][kk])); }
+    } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -115,7 +126,8 @@ __global__ __launch_bounds__(512, 2) void gemm128_kernel(GemmArgs<bf16_t> g) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) a[i][kk] = frag128(sa, wr * 64 + i * 16 + l15, 4 * kk + l4);
-    if (more) dma(kt + 2, s2);                          // the stage K-tile kt - 1 was read from
+    }
+    if (more && !((GPT_ABL128 & 1) && kt >= 2)) dma(kt + 2, s2);   // the stage K-tile kt - 1 was read from
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (wr == 1) {                                      // group 1: its pieces of kt + 1, before ITS barrier instance 2 (kt + 1)
       if (more) wait_vm<6>();
@@ -123,6 +135,7 @@ __global__ __launch_bounds__(512, 2) void gemm128_kernel(GemmArgs<bf16_t> g) {
     }
     SEG_BARRIER();
     __builtin_amdgcn_s_setprio(1);
+    if (!(GPT_ABL128 & 8))
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
