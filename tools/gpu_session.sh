@@ -1,4 +1,10 @@
+# One MI355X session: the whole GPU suite, smoke() and the default bench line (run through gpurun from the repo root).
 set -o pipefail
-SH="qkv64:1664:4608:1536:0 longk:1664:4608:6144:0"
-echo "abl 0 (product)"; timeout -k 10 100 python tools/gemm_bench.py --shapes $SH 2>&1 | grep -v amdgpu.ids | tail -2
-for a in 1 2 3 4 7 8 9 10; do echo "abl $a"; GPT_HIP_LIB=$PWD/g.pt_amd/lib/libgpt_hip_abl$a.so timeout -k 10 100 python tools/gemm_bench.py --shapes $SH 2>&1 | grep -v amdgpu.ids | tail -2 || exit 1; done
+mkdir -p gpurun_out
+timeout -k 10 1500 python -u -m pytest tests -x -q -m gpu --timeout 400 --timeout-method thread > gpurun_out/r3_gpu_all.log 2>&1; rc=$?; tail -3 gpurun_out/r3_gpu_all.log | cut -c1-300
+if grep -q "HSA_STATUS_ERROR\|Memory access fault" gpurun_out/r3_gpu_all.log; then echo FAULT; exit 1; fi
+[ $rc -eq 0 ] || { grep -E "^E |Error" gpurun_out/r3_gpu_all.log | head -20; exit $rc; }
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1 || { tail -5 gpurun_out/smoke.log; exit 1; }
+tail -1 gpurun_out/smoke.log
+timeout -k 10 500 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err || { tail -20 gpurun_out/bench.err; exit 1; }
+cut -c1-600 gpurun_out/bench.json
