@@ -126,6 +126,11 @@ int gpt_layernorm_bwd_part(const void* dy, int dy_dtype, const float* x, const f
                            float* part, int* n_blocks, int rows, int d, void* stream);
 int gpt_ln_partials_reduce(const LnPartCalls& calls, int d, void* stream);
 
+// ln_in (+ position embedding) and the first Block's ln1 in one launch (inference forward), for the widths _has() names
+bool gpt_layernorm_pair_has(int d);
+int gpt_layernorm_pair(const float* x, const float* g0, const float* b0, const float* add, int add_rows, float* x0, const float* g1,
+                       const float* b1, void* y, int out_dtype, int rows, int d, float eps, void* stream);
+
 // gpt_attention storing only the first t_out query rows of every sample, compactly ([B, t_out, d]); gather of the matching fp32
 // residual rows (the pruned last Block of an inference forward, model.cpp)
 int gpt_attention_rows(int dtype, const void* qkv, void* y, int B, int T, int t_out, int n_head, int hd, void* stream);

@@ -100,13 +100,19 @@ static int denoiser_forward(const gpt_model_t* m, const gpt_workspace_t* ws, con
   }();
   const bool prune = prune_on && !keep && L > 0 && m->n_out_tok < T && (size_t)(T - m->n_out_tok) * 4 * es >= (size_t)m->n_out_tok * 4;
 
-  // ln_in + position embedding (transformer.py:226, 308-309)
-  CHECK(gpt_layernorm(ws->enc, m->ln_in_w, m->ln_in_b, m->pos_emb, T, xbuf(0), GPT_F32, stat(0, 0), stat(0, 1), M, d, 1e-5f, stream));
-
-  // Every residual Linear is launched together with the LayerNorm that reads its result (gpt_gemm_resadd_layernorm: one
-  // fused pass at small batches, the two kernels otherwise): proj + ln2, mlp.2 + the next block's ln1 (ln_f after the last).
-  CHECK(gpt_layernorm(xbuf(0), m->layers[0].ln1_w, m->layers[0].ln1_b, nullptr, 0, lay(ws->h1, 0, d), dt, stat(1, 0), stat(1, 1), M, d,
-                      1e-5f, stream));
+  // ln_in + position embedding (transformer.py:226, 308-309), then the first Block's ln1: one launch in the inference forward
+  // (no statistics kept), two otherwise
+  static const bool ln_pair = [] { const char* e = getenv("GPT_LN_FUSE0"); return !e || atoi(e) != 0; }();   // 0: two launches (A/B)
+  if (ln_pair && !keep && L > 0 && gpt_layernorm_pair_has(d)) {
+    CHECK(gpt_layernorm_pair(ws->enc, m->ln_in_w, m->ln_in_b, m->pos_emb, T, xbuf(0), m->layers[0].ln1_w, m->layers[0].ln1_b,
+                             lay(ws->h1, 0, d), dt, M, d, 1e-5f, stream));
+  } else {
+    CHECK(gpt_layernorm(ws->enc, m->ln_in_w, m->ln_in_b, m->pos_emb, T, xbuf(0), GPT_F32, stat(0, 0), stat(0, 1), M, d, 1e-5f, stream));
+    // Every residual Linear is launched together with the LayerNorm that reads its result (gpt_gemm_resadd_layernorm: one
+    // fused pass at small batches, the two kernels otherwise): proj + ln2, mlp.2 + the next block's ln1 (ln_f after the last).
+    CHECK(gpt_layernorm(xbuf(0), m->layers[0].ln1_w, m->layers[0].ln1_b, nullptr, 0, lay(ws->h1, 0, d), dt, stat(1, 0), stat(1, 1), M, d,
+                        1e-5f, stream));
+  }
   for (int l = 0; l < L; ++l) {
     const gpt_layer_t& ly = m->layers[l];
     float* xin = xbuf(2 * l);

@@ -9,6 +9,25 @@ namespace {
 constexpr int ROWS_PER_BLOCK = 4;
 
 // NV = float4 per lane held in registers (d == NV * 256); NV == 0: generic d % 4 == 0, re-reads the row.
+// The element-wise steps the LayerNorm kernels of this file share.  The fused multiply-adds are written out and contraction is
+// off around them, so the kernels agree bit for bit with one another whatever the compiler would have contracted in each
+// (left to it, the one-row, two-row and paired kernels came out with different fma placements: results 1 ulp apart).
+__device__ __forceinline__ float ln_sum4(const float4& t) { return (t.x + t.y) + (t.z + t.w); }
+__device__ __forceinline__ float ln_sq4(const float4& t, float mean) {
+#pragma clang fp contract(off)
+  const float a = t.x - mean, b = t.y - mean, c = t.z - mean, e = t.w - mean;
+  return __builtin_fmaf(a, a, b * b) + __builtin_fmaf(c, c, e * e);
+}
+__device__ __forceinline__ float4 ln_affine4(const float4& t, float mean, float rstd, const float4& g, const float4& b) {
+#pragma clang fp contract(off)
+  float4 o;
+  o.x = __builtin_fmaf((t.x - mean) * rstd, g.x, b.x);
+  o.y = __builtin_fmaf((t.y - mean) * rstd, g.y, b.y);
+  o.z = __builtin_fmaf((t.z - mean) * rstd, g.z, b.z);
+  o.w = __builtin_fmaf((t.w - mean) * rstd, g.w, b.w);
+  return o;
+}
+
 template <int NV, typename OutT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ add,
@@ -25,28 +44,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       v[i] = xr[lane + i * 64];
-      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      s += ln_sum4(v[i]);
     }
   } else {
-    for (int c = lane; c < nv; c += 64) {
-      const float4 t = xr[c];
-      s += (t.x + t.y) + (t.z + t.w);
-    }
+    for (int c = lane; c < nv; c += 64) s += ln_sum4(xr[c]);
   }
   const float mean = wave_sum(s) / (float)d;
   float q = 0.f;
   if constexpr (NV > 0) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
-      q += (a * a + b * b) + (c * c + e * e);
-    }
+    for (int i = 0; i < NV; ++i) q += ln_sq4(v[i], mean);
   } else {
-    for (int c = lane; c < nv; c += 64) {
-      const float4 t = xr[c];
-      const float a = t.x - mean, b = t.y - mean, cc = t.z - mean, e = t.w - mean;
-      q += (a * a + b * b) + (cc * cc + e * e);
-    }
+    for (int c = lane; c < nv; c += 64) q += ln_sq4(xr[c], mean);
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
   if (lane == 0) {
@@ -58,12 +67,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   const float4* a4 = add ? reinterpret_cast<const float4*>(add + (int64_t)(row % add_rows) * d) : nullptr;
   OutT* yr = y + (int64_t)row * d;
   auto emit = [&](int c, const float4& t) {
-    const float4 g = g4[c], b = b4[c];
-    float4 o;
-    o.x = (t.x - mean) * rstd * g.x + b.x;
-    o.y = (t.y - mean) * rstd * g.y + b.y;
-    o.z = (t.z - mean) * rstd * g.z + b.z;
-    o.w = (t.w - mean) * rstd * g.w + b.w;
+    float4 o = ln_affine4(t, mean, rstd, g4[c], b4[c]);
     if (a4) {
       const float4 a = a4[c];
       o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
@@ -117,14 +121,11 @@ __global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict
     if (row >= rows) break;                                 // wave-uniform
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) s += (v[rr][i].x + v[rr][i].y) + (v[rr][i].z + v[rr][i].w);
+    for (int i = 0; i < NV; ++i) s += ln_sum4(v[rr][i]);
     const float mean = wave_sum(s) / (float)d;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const float a = v[rr][i].x - mean, b = v[rr][i].y - mean, c = v[rr][i].z - mean, e = v[rr][i].w - mean;
-      q += (a * a + b * b) + (c * c + e * e);
-    }
+    for (int i = 0; i < NV; ++i) q += ln_sq4(v[rr][i], mean);
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
     if (lane == 0) {
       if (mean_out) mean_out[row] = mean;
@@ -133,12 +134,7 @@ __global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict
     OutT* yr = y + (int64_t)row * d;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const float4 t = v[rr][i], g = gm[i], b = bt[i];
-      float4 o;
-      o.x = (t.x - mean) * rstd * g.x + b.x;
-      o.y = (t.y - mean) * rstd * g.y + b.y;
-      o.z = (t.z - mean) * rstd * g.z + b.z;
-      o.w = (t.w - mean) * rstd * g.w + b.w;
+      const float4 o = ln_affine4(v[rr][i], mean, rstd, gm[i], bt[i]);
       if constexpr (sizeof(OutT) == 4) {
         reinterpret_cast<float4*>(yr)[lane + i * 64] = o;
       } else {
@@ -147,6 +143,61 @@ __global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict
         p.y = pack_bf16x2(o.z, o.w);
         reinterpret_cast<uint2*>(yr)[lane + i * 64] = p;
       }
+    }
+  }
+}
+
+// ln_in + position embedding and the first Block's ln1 in one pass (inference forward): x0 = LN(x; g0, b0) + add -> fp32, then
+// y = LN(x0; g1, b1) -> OutT from the registers.  Per row the arithmetic and its order are those of two layernorm_kernel launches
+// (bit-identical); saves a launch and the re-read of x0.
+template <int NV, typename OutT>
+__global__ __launch_bounds__(256) void layernorm_pair_kernel(const float* __restrict__ x, const float* __restrict__ g0, const float* __restrict__ b0,
+                                                             const float* __restrict__ add, int add_rows, float* __restrict__ x0,
+                                                             const float* __restrict__ g1, const float* __restrict__ b1,
+                                                             OutT* __restrict__ y, int rows, float eps) {
+  constexpr int d = NV * 256;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * d);
+  float4 v[NV];
+  auto norm = [&](const float* __restrict__ gamma, const float* __restrict__ beta, const float4* a4) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += ln_sum4(v[i]);
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) q += ln_sq4(v[i], mean);
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + i * 64;
+      float4 o = ln_affine4(v[i], mean, rstd, reinterpret_cast<const float4*>(gamma)[c], reinterpret_cast<const float4*>(beta)[c]);
+      if (a4) {
+        const float4 a = a4[c];
+        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+      }
+      v[i] = o;
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = xr[lane + i * 64];
+  norm(g0, b0, reinterpret_cast<const float4*>(add + (int64_t)(row % add_rows) * d));
+  float4* x0r = reinterpret_cast<float4*>(x0 + (int64_t)row * d);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) x0r[lane + i * 64] = v[i];
+  norm(g1, b1, nullptr);
+  OutT* yr = y + (int64_t)row * d;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if constexpr (sizeof(OutT) == 4) {
+      reinterpret_cast<float4*>(yr)[lane + i * 64] = v[i];
+    } else {
+      uint2 p;
+      p.x = pack_bf16x2(v[i].x, v[i].y);
+      p.y = pack_bf16x2(v[i].z, v[i].w);
+      reinterpret_cast<uint2*>(yr)[lane + i * 64] = p;
     }
   }
 }
@@ -191,6 +242,34 @@ extern "C" int gpt_layernorm(const float* x, const float* gamma, const float* be
   hipStream_t s = (hipStream_t)stream;
   if (out_dtype == GPT_F32) return launch<float>(x, gamma, beta, add, add_rows, y, mean, rstd, rows, d, eps, s);
   return launch<bf16_t>(x, gamma, beta, add, add_rows, y, mean, rstd, rows, d, eps, s);
+}
+
+// x0 = LN(x; g0, b0) + add[row % add_rows] (fp32), y = LN(x0; g1, b1) (out_dtype), one launch.  Widths 1536, 2048 and 3072 only
+// (gpt_layernorm_pair_has): for any other the caller makes the two gpt_layernorm calls
+bool gpt_layernorm_pair_has(int d) { return d == 1536 || d == 2048 || d == 3072; }
+
+int gpt_layernorm_pair(const float* x, const float* g0, const float* b0, const float* add, int add_rows, float* x0, const float* g1,
+                       const float* b1, void* y, int out_dtype, int rows, int d, float eps, void* stream) {
+  GPT_REQUIRE(x && g0 && b0 && add && add_rows > 0 && x0 && g1 && b1 && y && rows > 0, "gpt_layernorm_pair: bad operands");
+  GPT_REQUIRE(gpt_layernorm_pair_has(d), "gpt_layernorm_pair: no instance for d=%d", d);
+  GPT_REQUIRE(out_dtype == GPT_F32 || out_dtype == GPT_BF16, "gpt_layernorm_pair: bad out_dtype %d", out_dtype);
+  GPT_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)x0 % 16) == 0 && ((uintptr_t)y % 8) == 0 && ((uintptr_t)g0 % 16) == 0 &&
+                  ((uintptr_t)b0 % 16) == 0 && ((uintptr_t)g1 % 16) == 0 && ((uintptr_t)b1 % 16) == 0 && ((uintptr_t)add % 16) == 0,
+              "gpt_layernorm_pair: operands must be 16-byte aligned");
+  const dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define LNP(NV)                                                                                                                   \
+  do {                                                                                                                            \
+    if (out_dtype == GPT_F32)                                                                                                     \
+      hipLaunchKernelGGL((layernorm_pair_kernel<NV, float>), grid, block, 0, s, x, g0, b0, add, add_rows, x0, g1, b1, (float*)y, rows, eps); \
+    else                                                                                                                          \
+      hipLaunchKernelGGL((layernorm_pair_kernel<NV, bf16_t>), grid, block, 0, s, x, g0, b0, add, add_rows, x0, g1, b1, (bf16_t*)y, rows, eps); \
+  } while (0)
+  if (d == 1536) LNP(6);
+  else if (d == 2048) LNP(8);
+  else LNP(12);
+#undef LNP
+  return gpt_launch_status("gpt_layernorm_pair");
 }
 
 // dst[b * t_out + r, :] = src[b * T + r, :] for r < t_out: the residual-stream rows of the tokens the decoder reads, compacted for

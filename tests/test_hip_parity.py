@@ -347,6 +347,42 @@ def test_forward_full_size_vs_oracle(case):
     assert float((out16 - ref).abs().max()) / scale < 3e-2
 
 
+def test_paired_input_layernorms_are_bit_identical_to_two_launches():
+    """The inference forward runs ln_in + position embedding and the first Block's ln1 as one launch at the full-size widths
+    (gpt_layernorm_pair, csrc/norm.hip; transformer.py:226, 308-309 and Block.ln_1): same arithmetic in the same order, so
+    the denoiser output must equal, bit for bit, the one from two launches (GPT_LN_FUSE0=0, a process of its own: the switch is
+    read once).  B = 5 takes the one-row-per-wave second LayerNorm, B = 320 (8320 rows) the two-rows-per-wave one."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from tests.test_hip_parity import build, DEV
+from tests.cases import make_inputs
+out = {}
+for case in ("mnist", "cifar"):
+    for dtype in ("fp32", "bf16"):
+        m, plan, sd = build(case, dtype, seed=3)
+        for B in (5, 320):
+            x, t, lt, lp, xp = (v.to(DEV) for v in make_inputs(case, B=B, seed=B))
+            with torch.no_grad():
+                out["%%s.%%s.%%d" %% (case, dtype, B)] = m(x, t, lt, lp, xp).float().cpu()
+torch.save(out, sys.argv[1])
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for flag in ("1", "0"):
+            path = os.path.join(td, f"f{flag}.pt")
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, GPT_LN_FUSE0=flag), timeout=280)
+            outs.append(torch.load(path, weights_only=True))
+    assert len(outs[0]) == 8
+    for k in outs[0]:
+        assert torch.isfinite(outs[0][k]).all(), k
+        assert torch.equal(outs[0][k], outs[1][k]), (k, float((outs[0][k] - outs[1][k]).abs().max()))
+
+
 @pytest.mark.parametrize("sizes,policy,chunk,absolute,n_embd,n_head", [
     ([7840, 10, 100, 10], "layer_by_layer", None, True, 128, 4),     # 12 tokens, one of them 7840 wide (the cartpole policy)
     ([432, 4608, 320, 10], "chunk_within_input", 1000, False, 192, 2),  # delta-loss conditioning only: 2 scalar tokens
