@@ -287,6 +287,7 @@ def main():
     backend = os.environ.get("GPT_BENCH_BACKEND", "nccl")
     if os.environ.get("GPT_BENCH_ONE_GPU") == "1":
         local = 0
+    install_term_guard(rank)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1 or os.environ.get("GPT_DP_REHEARSE") == "1":   # one-rank rehearsal of the RCCL calls: g.pt_amd/dp.py exchanging()
@@ -321,10 +322,48 @@ def main():
                 if rank == 0 and world == 1 and not args.no_cpu_baseline:
                     line["cpu_baseline_train"] = guarded(lambda: cpu_baseline_train("mnist"), rank, line, "cpu_baseline_train", 400.0)
     if rank == 0:
+        _PENDING["printed"] = True
         print(json.dumps(line), flush=True)
     if dp.exchanging():
         dist.barrier()
         dist.destroy_process_group()
+
+
+# What rank 0 would still owe the caller if the process were ended now: the line measured so far and the leg that was running.
+_PENDING = {"line": None, "key": None, "printed": False}
+
+
+def install_term_guard(rank):
+    """If another rank dies inside a secondary leg, the launcher ends the survivors with SIGTERM (SIGKILL half a minute later) -
+    usually while rank 0's main thread sits inside a GPU wait or a collective, where a Python-level handler would never run.  The
+    C-level handler only writes the signal number to a wake-up socket; a helper thread reads it, prints the headline line measured
+    so far with an error object under the leg that was running, and leaves with a non-zero code.  Nothing is printed when no
+    headline exists yet or the line is already out."""
+    import signal
+    import socket
+    import threading
+    if rank != 0 or threading.current_thread() is not threading.main_thread():
+        return
+    rd, wr = socket.socketpair()
+    wr.setblocking(False)
+    signal.signal(signal.SIGTERM, lambda *_: None)        # a Python handler must exist for the wake-up byte to be written
+    signal.set_wakeup_fd(wr.fileno(), warn_on_full_buffer=False)
+    install_term_guard.keep = (rd, wr)
+
+    def watch():
+        while True:
+            got = rd.recv(16)
+            if not got or signal.SIGTERM in got:
+                break
+        line, key = _PENDING["line"], _PENDING["key"] or "run"
+        if line is not None and not _PENDING["printed"]:
+            line[key] = {"error": "terminated (SIGTERM) during this measurement: another rank failed or the launcher gave up"}
+            print(json.dumps(line, default=str), flush=True)
+        sys.stderr.write(f"bench.py: SIGTERM during '{key}'\n")
+        sys.stderr.flush()
+        os._exit(143)
+
+    threading.Thread(target=watch, daemon=True).start()
 
 
 def guarded(fn, rank, line, key, limit_s):
@@ -335,7 +374,8 @@ def guarded(fn, rank, line, key, limit_s):
     import threading
 
     def give_up():
-        if rank == 0:
+        if rank == 0 and not _PENDING["printed"]:
+            _PENDING["printed"] = True
             line[key] = {"error": f"did not finish within {limit_s:.0f} s (hung step or collective): process aborted, exit code 3"}
             print(json.dumps(line), flush=True)
         sys.stderr.write(f"bench.py: '{key}' measurement exceeded {limit_s:.0f} s; stacks follow\n")
@@ -346,6 +386,7 @@ def guarded(fn, rank, line, key, limit_s):
     timer = threading.Timer(limit_s, give_up)
     timer.daemon = True
     timer.start()
+    _PENDING.update(line=line, key=key)
     try:
         return fn()
     except Exception as e:  # noqa: BLE001 - the headline line must survive a failure of a secondary measurement

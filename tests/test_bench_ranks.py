@@ -63,3 +63,35 @@ def test_bare_multi_gpu_invocation_spawns_ranks_before_any_gpu_call(monkeypatch)
     cmd = seen["cmd"]
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "2"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]
+
+
+def test_headline_survives_sigterm_during_a_secondary_leg():
+    """bench.py install_term_guard: rank 0 blocked inside a C call (as in a GPU wait whose peers are gone) is ended by the
+    launcher's SIGTERM; the line measured so far must still be printed, with an error object under the running leg, and the exit
+    code must be non-zero.  No GPU: the guard and `guarded` are driven directly."""
+    import json
+    import signal
+    import subprocess as sp
+    import sys
+    import time
+    code = r'''
+import sys, threading
+sys.argv = ["bench.py"]
+sys.path.insert(0, %r)
+import bench
+bench.install_term_guard(0)
+line = {"metric": "sampled param-vectors/sec (DDPM)", "value": 55.0}
+print("ready", flush=True)
+bench.guarded(lambda: threading.Event().wait(60), 0, line, "train", 100.0)     # a lock wait: Python-level handlers cannot run
+print("not reached", flush=True)
+''' % ROOT
+    proc = sp.Popen([sys.executable, "-c", code], stdout=sp.PIPE, stderr=sp.PIPE, text=True, cwd=ROOT)
+    assert proc.stdout.readline().strip() == "ready"
+    time.sleep(0.5)
+    proc.send_signal(signal.SIGTERM)
+    out, err = proc.communicate(timeout=30)
+    assert proc.returncode == 143, (proc.returncode, out, err[-2000:])
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and "not reached" not in out, out
+    got = json.loads(lines[0])
+    assert got["value"] == 55.0 and "SIGTERM" in got["train"]["error"]
