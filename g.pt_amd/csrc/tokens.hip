@@ -61,7 +61,7 @@ __global__ void scalar_tokens_kernel(const int64_t* __restrict__ t, const void* 
 // costs one exposed memory latency, so r01's 32-element chunks (4 MFMAs per wave between two latencies) made these kernels
 // latency-bound: 61 / 48 us per sampling step at B = 320 for ~100 MB of traffic (r02: see DESIGN.md section 4).
 constexpr int MAX_TOK = 40;
-constexpr int TB = 64, TN = 128;
+constexpr int TB = 64;             // batch rows per workgroup; output columns: 64 NJ (NJ = 32-column MFMA tiles per wave, 1 or 2)
 constexpr int KC_PAD = 32;          // the host pads encoder weight rows to a multiple of this (denoiser.py)
 
 struct EncTok {
@@ -94,8 +94,8 @@ struct Pitch {
   static constexpr int value = KC * sizeof(T) + 16;  // bytes per LDS row: 272 (bf16, KC 128) / 80 (bf16, 32) / 144 (fp32, 32)
 };
 
-template <typename T, int KC>
-__device__ __forceinline__ void mma_chunk(const char* ldsA, const char* ldsW, int wr, int wc, int lane, f32x16 (&acc)[2]) {
+template <typename T, int KC, int NJ>
+__device__ __forceinline__ void mma_chunk(const char* ldsA, const char* ldsW, int wr, int wc, int lane, f32x16 (&acc)[NJ]) {
   constexpr int P = Pitch<T, KC>::value;
   const int r = lane & 31, hh = lane >> 5;
   if constexpr (sizeof(T) == 2) {
@@ -103,8 +103,8 @@ __device__ __forceinline__ void mma_chunk(const char* ldsA, const char* ldsW, in
     for (int s = 0; s < KC / 16; ++s) {
       const bf16x8 a = *reinterpret_cast<const bf16x8*>(ldsA + (wr * 32 + r) * P + (s * 16 + hh * 8) * 2);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(ldsW + (wc * 64 + j * 32 + r) * P + (s * 16 + hh * 8) * 2);
+      for (int j = 0; j < NJ; ++j) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(ldsW + (wc * 32 * NJ + j * 32 + r) * P + (s * 16 + hh * 8) * 2);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
       }
     }
@@ -113,8 +113,8 @@ __device__ __forceinline__ void mma_chunk(const char* ldsA, const char* ldsW, in
     for (int q = 0; q < KC / 8; ++q) {
       const float4 a = *reinterpret_cast<const float4*>(ldsA + (wr * 32 + r) * P + (q * 8 + hh * 4) * 4);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float4 b = *reinterpret_cast<const float4*>(ldsW + (wc * 64 + j * 32 + r) * P + (q * 8 + hh * 4) * 4);
+      for (int j = 0; j < NJ; ++j) {
+        const float4 b = *reinterpret_cast<const float4*>(ldsW + (wc * 32 * NJ + j * 32 + r) * P + (q * 8 + hh * 4) * 4);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[j], 0, 0, 0);
@@ -163,9 +163,9 @@ struct Stage {
   }
 };
 
-template <typename T, int KC>
+template <typename T, int KC, int NJ>
 __global__ __launch_bounds__(256) void encode_kernel(EncArgs g) {
-  constexpr int P = Pitch<T, KC>::value;
+  constexpr int P = Pitch<T, KC>::value, TN = 64 * NJ;
   __shared__ __attribute__((aligned(16))) char smem[(TB + TN) * P];
   char* ldsA = smem;
   char* ldsW = smem + TB * P;
@@ -173,9 +173,9 @@ __global__ __launch_bounds__(256) void encode_kernel(EncArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
   const int b0 = blockIdx.y * TB, n0 = blockIdx.x * TN;
-  f32x16 acc[2];
+  f32x16 acc[NJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
@@ -255,21 +255,21 @@ __global__ __launch_bounds__(256) void encode_kernel(EncArgs g) {
       __syncthreads();
       load_a(a0, min(c + 2, last) * KC);
       w0.load((const T*)tk.w, tk.w_ld, n0, g.d, min(c + 2, last) * KC, kw, tid);
-      mma_chunk<T, KC>(ldsA, ldsW, wr, wc, lane, acc);
+      mma_chunk<T, KC, NJ>(ldsA, ldsW, wr, wc, lane, acc);
       __syncthreads();
       store_a(a1);
       w1.store(ldsW, tid);
       __syncthreads();
       load_a(a1, min(c + 3, last) * KC);
       w1.load((const T*)tk.w, tk.w_ld, n0, g.d, min(c + 3, last) * KC, kw, tid);
-      mma_chunk<T, KC>(ldsA, ldsW, wr, wc, lane, acc);
+      mma_chunk<T, KC, NJ>(ldsA, ldsW, wr, wc, lane, acc);
       __syncthreads();
     }
     if (nchunk & 1) {                               // stage 0 holds the last chunk
       store_a(a0);
       w0.store(ldsW, tid);
       __syncthreads();
-      mma_chunk<T, KC>(ldsA, ldsW, wr, wc, lane, acc);
+      mma_chunk<T, KC, NJ>(ldsA, ldsW, wr, wc, lane, acc);
     }
   };
   if (avec == 4) run(std::integral_constant<int, 4>{});
@@ -277,8 +277,8 @@ __global__ __launch_bounds__(256) void encode_kernel(EncArgs g) {
   else run(std::integral_constant<int, 1>{});
   const int r = lane & 31, hh = lane >> 5;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wc * 64 + j * 32 + r;
+  for (int j = 0; j < NJ; ++j) {
+    const int n = n0 + wc * 32 * NJ + j * 32 + r;
     if (n >= g.d) continue;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -289,9 +289,9 @@ __global__ __launch_bounds__(256) void encode_kernel(EncArgs g) {
 }
 
 // d % KC == 0 (host)
-template <typename T, int KC>
+template <typename T, int KC, int NJ>
 __global__ __launch_bounds__(256) void decode_kernel(DecArgs g) {
-  constexpr int P = Pitch<T, KC>::value;
+  constexpr int P = Pitch<T, KC>::value, TN = 64 * NJ;
   __shared__ __attribute__((aligned(16))) char smem[(TB + TN) * P];
   char* ldsA = smem;
   char* ldsW = smem + TB * P;
@@ -301,9 +301,9 @@ __global__ __launch_bounds__(256) void decode_kernel(DecArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
   const int b0 = blockIdx.y * TB;
-  f32x16 acc[2];
+  f32x16 acc[NJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
@@ -324,26 +324,26 @@ __global__ __launch_bounds__(256) void decode_kernel(DecArgs g) {
     __syncthreads();
     f0.load(feat, fld, b0, g.B, min(c + 2, last) * KC, g.d, tid);
     w0.load((const T*)tk.w, g.d, n0, tk.n, min(c + 2, last) * KC, g.d, tid);
-    mma_chunk<T, KC>(ldsA, ldsW, wr, wc, lane, acc);
+    mma_chunk<T, KC, NJ>(ldsA, ldsW, wr, wc, lane, acc);
     __syncthreads();
     f1.store(ldsA, tid);
     w1.store(ldsW, tid);
     __syncthreads();
     f1.load(feat, fld, b0, g.B, min(c + 3, last) * KC, g.d, tid);
     w1.load((const T*)tk.w, g.d, n0, tk.n, min(c + 3, last) * KC, g.d, tid);
-    mma_chunk<T, KC>(ldsA, ldsW, wr, wc, lane, acc);
+    mma_chunk<T, KC, NJ>(ldsA, ldsW, wr, wc, lane, acc);
     __syncthreads();
   }
   if (nchunk & 1) {
     f0.store(ldsA, tid);
     w0.store(ldsW, tid);
     __syncthreads();
-    mma_chunk<T, KC>(ldsA, ldsW, wr, wc, lane, acc);
+    mma_chunk<T, KC, NJ>(ldsA, ldsW, wr, wc, lane, acc);
   }
   const int r = lane & 31, hh = lane >> 5;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wc * 64 + j * 32 + r;
+  for (int j = 0; j < NJ; ++j) {
+    const int n = n0 + wc * 32 * NJ + j * 32 + r;
     if (n >= tk.n) continue;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -357,6 +357,17 @@ __global__ __launch_bounds__(256) void decode_kernel(DecArgs g) {
 }
 
 }  // namespace
+
+// 32-column MFMA tiles per wave: 2 (128 output columns per workgroup) when that already gives the chip a workgroup per CU, else 1
+// (64 columns, twice the workgroups).  These kernels are latency-bound chains of K chunks: at B = 64 the decoder launched 66
+// workgroups of 128 columns on 256 CUs (29 us for 24.5 MB of weights).
+static int pick_nj(int wgs128) {
+  static const int forced = [] { const char* e = getenv("GPT_TOKENS_NJ"); return e ? atoi(e) : 0; }();   // 1 / 2: force (A/B)
+  if (forced == 1 || forced == 2) return forced;
+  int dev = 0, n_cu = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+  return wgs128 >= n_cu ? 2 : 1;
+}
 
 extern "C" int gpt_scalar_tokens(const int64_t* t, const void* loss_target, const void* loss_prev, int loss_is_f64,
                                  const float* freqs, int nfreq, int n_scalar, float* out, int B, void* stream) {
@@ -388,11 +399,18 @@ extern "C" int gpt_encode_tokens_subset(int dtype, int n_sel, const float* const
     g.tok[i] = EncTok{host_src[i], host_w[i], host_src_ld[i], host_w_ld[i], host_k[i], slot};
   }
   g.out = out; g.n_tok = n_tok; g.B = B; g.d = d;
-  const dim3 grid((d + TN - 1) / TN, (B + TB - 1) / TB, n_sel), block(256);
+  const int nj = pick_nj((d + 127) / 128 * ((B + TB - 1) / TB) * n_sel);
+  const dim3 grid((d + 64 * nj - 1) / (64 * nj), (B + TB - 1) / TB, n_sel), block(256);
   static const bool wide = [] { const char* e = getenv("GPT_TOKENS_KC128"); return !e || atoi(e) != 0; }();   // 0: r01's chunks (A/B)
-  if (dtype == GPT_BF16 && wide) hipLaunchKernelGGL((encode_kernel<bf16_t, 128>), grid, block, 0, (hipStream_t)stream, g);
-  else if (dtype == GPT_BF16) hipLaunchKernelGGL((encode_kernel<bf16_t, 32>), grid, block, 0, (hipStream_t)stream, g);
-  else hipLaunchKernelGGL((encode_kernel<float, 32>), grid, block, 0, (hipStream_t)stream, g);
+#define ENC(T, KC)                                                                                          \
+  do {                                                                                                      \
+    if (nj == 1) hipLaunchKernelGGL((encode_kernel<T, KC, 1>), grid, block, 0, (hipStream_t)stream, g);     \
+    else hipLaunchKernelGGL((encode_kernel<T, KC, 2>), grid, block, 0, (hipStream_t)stream, g);             \
+  } while (0)
+  if (dtype == GPT_BF16 && wide) ENC(bf16_t, 128);
+  else if (dtype == GPT_BF16) ENC(bf16_t, 32);
+  else ENC(float, 32);
+#undef ENC
   return gpt_launch_status("gpt_encode_tokens");
 }
 
@@ -419,10 +437,17 @@ extern "C" int gpt_decode_tokens(int dtype, int n_tok, const void* feat, int T, 
     max_n = host_n[j] > max_n ? host_n[j] : max_n;
   }
   g.feat = feat; g.resid = resid; g.out = out; g.n_tok = n_tok; g.T = T; g.B = B; g.d = d; g.D = D;
-  const dim3 grid((max_n + TN - 1) / TN, (B + TB - 1) / TB, n_tok), block(256);
+  const int nj = pick_nj((max_n + 127) / 128 * ((B + TB - 1) / TB) * n_tok);
+  const dim3 grid((max_n + 64 * nj - 1) / (64 * nj), (B + TB - 1) / TB, n_tok), block(256);
   static const bool wide = [] { const char* e = getenv("GPT_TOKENS_KC128"); return !e || atoi(e) != 0; }();
-  if (dtype == GPT_BF16 && wide && d % 128 == 0) hipLaunchKernelGGL((decode_kernel<bf16_t, 128>), grid, block, 0, (hipStream_t)stream, g);
-  else if (dtype == GPT_BF16) hipLaunchKernelGGL((decode_kernel<bf16_t, 32>), grid, block, 0, (hipStream_t)stream, g);
-  else hipLaunchKernelGGL((decode_kernel<float, 32>), grid, block, 0, (hipStream_t)stream, g);
+#define DEC(T, KC)                                                                                          \
+  do {                                                                                                      \
+    if (nj == 1) hipLaunchKernelGGL((decode_kernel<T, KC, 1>), grid, block, 0, (hipStream_t)stream, g);     \
+    else hipLaunchKernelGGL((decode_kernel<T, KC, 2>), grid, block, 0, (hipStream_t)stream, g);             \
+  } while (0)
+  if (dtype == GPT_BF16 && wide && d % 128 == 0) DEC(bf16_t, 128);
+  else if (dtype == GPT_BF16) DEC(bf16_t, 32);
+  else DEC(float, 32);
+#undef DEC
   return gpt_launch_status("gpt_decode_tokens");
 }
