@@ -139,7 +139,7 @@ def _scratch(eng, B, slots=1):
 def _grouped_wgrads(eng, B):
     """True where gpt_denoiser_backward computes the Blocks' weight gradients by the grouped TN launch."""
     dec = eng.model.decoder
-    return eng.code == L.BF16 and (B * dec.block_size) % 64 == 0 and dec.n_embd % 256 == 0 and \
+    return eng.code == L.BF16 and dec.n_embd % 256 == 0 and \
         os.environ.get("GPT_WGRAD_TN", "1") != "0"
 
 

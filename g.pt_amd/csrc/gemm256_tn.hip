@@ -14,7 +14,8 @@
 //    two reads give a lane its 8 k-values.  16-byte chunk c of LDS row r is stored at chunk
 //    c ^ ((r & 3) << 2) ^ (((r >> 3) & 1) << 1): the four rows of a block sit in four different 64-byte bank groups and
 //    the two groups of a 32-lane half (rows 8 apart, same columns) in the two 32-byte halves of them: conflict-free.
-// Needs R % 64 == 0, I % 256 == 0, J % 256 == 0 (the host falls back to transposes + the NT kernel otherwise).
+// Needs I % 256 == 0, J % 256 == 0 (the host falls back to transposes + the NT kernel otherwise).  Any R: the rows of the last
+// K-tile beyond R come from a 16-byte block of zeros for P and from row R - 1 (finite values times zero) for Q.
 #include "gemm_common.h"
 #include <stdlib.h>
 
@@ -25,6 +26,9 @@ constexpr int TRB = 256;             // bytes per LDS row (128 bf16 columns)
 constexpr int THALF = 64 * TRB;      // 16 KiB half-tile: 64 r-rows
 constexpr int TBUF = 4 * THALF;      // P-h0 | P-h1 | Q-h0 | Q-h1
 constexpr int TLDS_BYTES = 2 * TBUF;  // 128 KiB
+
+// what the LDS-DMA reads for the P rows past the end of a ragged contraction (every lane the same 16 bytes)
+__device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
 
 typedef short v4s __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4s* lds_v4s_ptr;
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(TnGroup grp) {
   const int gb = tile / (tiles_m * GROUP_N), grem = tile - gb * (tiles_m * GROUP_N);
   const int gw = min(GROUP_N, tiles_n - gb * GROUP_N);
   const int m0 = (grem / gw) * 256, n0 = (gb * GROUP_N + grem % gw) * 256;   // output rows (P columns) / columns (Q columns)
-  const int nk_all = g.K / 64, nk_span = (nk_all + ksplit - 1) / ksplit, kt0 = span * nk_span;
+  const int nk_all = (g.K + 63) / 64, nk_span = (nk_all + ksplit - 1) / ksplit, kt0 = span * nk_span;
   const int nk = min(nk_span, nk_all - kt0);
   if (nk <= 0) return;                                      // workgroup-uniform
 
@@ -87,22 +91,31 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(TnGroup grp) {
   // lane -> (row = lane >> 4, chunk = lane & 15) of the piece, the chunk's logical position un-swizzled
   const T* srcP[2][2];  // [half][piece]
   const T* srcQ[2][2];
+  const T* endQ[2][2];  // the same columns of row R - 1: what a Q row past the end reads instead (its P partner is zero)
+  const T* endP[2][2];  // zeros
+  int left[2];          // rows of this span from the piece's row of K-tile 0 to the end of the contraction (<= 0: none)
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     const int lr = wid * 8 + p * 4 + (lane >> 4);
     const int lc = (lane & 15) ^ ((lr & 3) << 2) ^ (((lr >> 3) & 1) << 1);   // logical 16-byte chunk (8 columns) of the 128-column row
     const int e = lc * 8;
+    left[p] = g.K - (kt0 * 64 + lr);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       srcP[h][p] = g.A + ((int64_t)kt0 * 64 + lr) * g.lda + m0 + h * 128 + e;
       srcQ[h][p] = g.W + ((int64_t)kt0 * 64 + lr) * g.ldw + n0 + h * 128 + e;
+      endQ[h][p] = g.W + ((int64_t)g.K - 1) * g.ldw + n0 + h * 128 + e;
+      endP[h][p] = reinterpret_cast<const T*>(g_zero16);
     }
   }
   const int64_t stepP = 64 * g.lda, stepQ = 64 * g.ldw;
-  auto dma = [&](const T* const (&src)[2], int64_t step, int kt, int slot) {
+  // (only the last K-tile of a ragged contraction ever takes `end`: two selects per instruction otherwise)
+  auto dma = [&](const T* const (&src)[2], const T* const (&end)[2], int64_t step, int kt, int slot) {
     char* dst = smem + (kt & 1) * TBUF + slot * THALF + wid * 2048;
-    __builtin_amdgcn_global_load_lds((gptr_t)(src[0] + kt * step), (lptr_t)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(src[1] + kt * step), (lptr_t)(dst + 1024), 16, 0, 0);
+    const T* s0 = kt * 64 < left[0] ? src[0] + kt * step : end[0];
+    const T* s1 = kt * 64 < left[1] ? src[1] + kt * step : end[1];
+    __builtin_amdgcn_global_load_lds((gptr_t)s0, (lptr_t)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)s1, (lptr_t)(dst + 1024), 16, 0, 0);
   };
 
   // 16x16x32 MFMAs (higher sustained clock than 32x32x16, see gemm256.hip): 8 x 4 accumulator tiles of 16 x 16 per wave
@@ -115,10 +128,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(TnGroup grp) {
 #pragma unroll
   for (int t = 0; t < 2; ++t)
     if (t < nk) {
-      dma(srcP[0], stepP, t, 0);
-      dma(srcQ[0], stepQ, t, 2);
-      dma(srcQ[1], stepQ, t, 3);
-      dma(srcP[1], stepP, t, 1);
+      dma(srcP[0], endP[0], stepP, t, 0);
+      dma(srcQ[0], endQ[0], stepQ, t, 2);
+      dma(srcQ[1], endQ[1], stepQ, t, 3);
+      dma(srcP[1], endP[1], stepP, t, 1);
     }
 
   // transposed-read addresses: 16-lane group gq reads the block rows 8 gq + q (then + 4), columns e0 + 4 p .. + 3
@@ -182,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(TnGroup grp) {
     read_q(b0, buf + 2 * THALF);
     read_p(a, buf);
     read_q(b1, buf + 3 * THALF);
-    if (kt >= 1 && !last) dma(srcP[1], stepP, kt + 1, 1);
+    if (kt >= 1 && !last) dma(srcP[1], endP[1], stepP, kt + 1, 1);
     SEG_READS_DONE();
     SEG_BARRIER();
     __builtin_amdgcn_s_setprio(1);
@@ -195,9 +208,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(TnGroup grp) {
     SEG_BARRIER();
     read_p(a, buf + THALF);
     if (steady) {
-      dma(srcP[0], stepP, kt + 2, 0);
-      dma(srcQ[0], stepQ, kt + 2, 2);
-      dma(srcQ[1], stepQ, kt + 2, 3);
+      dma(srcP[0], endP[0], stepP, kt + 2, 0);
+      dma(srcQ[0], endQ[0], stepQ, kt + 2, 2);
+      dma(srcQ[1], endQ[1], stepQ, kt + 2, 3);
     }
     SEG_READS_DONE();
     SEG_BARRIER();
@@ -289,7 +302,7 @@ int launch_tn(TnGroup& grp, hipStream_t s) {
     tiles += (grp.g[p].M / 256) * (grp.g[p].N / 256);
     flops += 2.0 * grp.g[p].M * grp.g[p].N * grp.g[p].K;
   }
-  grp.ksplit = EPI == GPT_EPI_ACCUM_F32 ? pick_tn_spans(tiles, grp.g[0].K / 64) : 1;   // spans add with atomics: accumulating only
+  grp.ksplit = EPI == GPT_EPI_ACCUM_F32 ? pick_tn_spans(tiles, (grp.g[0].K + 63) / 64) : 1;   // spans add with atomics: accumulating only
   grp.off[0] = 0;
   for (int p = 0; p < grp.n; ++p) grp.off[p + 1] = grp.off[p] + (grp.g[p].M / 256) * (grp.g[p].N / 256) * grp.ksplit;
   const bool rec = g_prof.on && g_prof.n < GemmProf::CAP;
@@ -307,8 +320,8 @@ int launch_tn(TnGroup& grp, hipStream_t s) {
 
 static int tn_check(const void* P, int64_t ldp, const void* Q, int64_t ldq, const float* C, int64_t ldc, int I, int J, int R) {
   GPT_REQUIRE(P && Q && C, "gpt_gemm_tn: null operand");
-  GPT_REQUIRE(I > 0 && J > 0 && R > 0 && I % 256 == 0 && J % 256 == 0 && R % 64 == 0,
-              "gpt_gemm_tn: need I %% 256 == 0, J %% 256 == 0, R %% 64 == 0 (got I=%d J=%d R=%d)", I, J, R);
+  GPT_REQUIRE(I > 0 && J > 0 && R > 0 && I % 256 == 0 && J % 256 == 0,
+              "gpt_gemm_tn: need I %% 256 == 0, J %% 256 == 0, R > 0 (got I=%d J=%d R=%d)", I, J, R);
   GPT_REQUIRE(ldp >= I && ldq >= J && ldc >= J && ldp % 8 == 0 && ldq % 8 == 0 && ldc % 4 == 0, "gpt_gemm_tn: bad leading dimensions");
   GPT_REQUIRE(((uintptr_t)P % 16) == 0 && ((uintptr_t)Q % 16) == 0 && ((uintptr_t)C % 16) == 0, "gpt_gemm_tn: operands must be 16-byte aligned");
   return 0;

@@ -42,7 +42,7 @@ static int validate(const gpt_model_t* m, const gpt_workspace_t* ws, int B, cons
 // Training (kept activations): the last Block behind its attention, the final LayerNorm and the decoder touch only the rows of the
 // tokens the decoder reads (the loss does not depend on the others: their rows of the last Block's projection / MLP are dead
 // work in the forward and all-zero gradients in the backward).  Forward and backward drivers must agree, so both ask this:
-// bf16 on the grouped TN weight-gradient route, and both row counts multiples of the TN kernel's 64-row K-tiles.
+// bf16 on the grouped TN weight-gradient route (any row count: the TN kernel zero-fills a ragged last K-tile).
 static bool prune_last_train(const gpt_model_t* m, int B) {
   static const bool on = [] {
     const char* e = getenv("GPT_PRUNE_LAST_TRAIN");   // 0: all rows (cross-check, A/B)
@@ -50,7 +50,8 @@ static bool prune_last_train(const gpt_model_t* m, int B) {
     return (!e || atoi(e) != 0) && (!tn || atoi(tn) != 0);
   }();
   const int To = m->n_out_tok, T = m->T;
-  return on && m->dtype == GPT_BF16 && m->n_layer > 0 && To < T && (B * T) % 64 == 0 && (B * To) % 64 == 0 && m->d % 256 == 0;
+  (void)B;
+  return on && m->dtype == GPT_BF16 && m->n_layer > 0 && To < T && m->d % 256 == 0;
 }
 
 static int denoiser_forward(const gpt_model_t* m, const gpt_workspace_t* ws, const float* x, const int64_t* t,
@@ -316,7 +317,7 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
   };
   auto wgrad = [&](const void* dY, int n_out, const void* X, int k_in, float* gW) -> int {
     // the TN kernel cuts the row range into spans when the weight has few 256 x 256 tiles (gemm256_tn.hip)
-    if (use_tn && dt == GPT_BF16 && M % 64 == 0 && n_out % 256 == 0 && k_in % 256 == 0)
+    if (use_tn && dt == GPT_BF16 && n_out % 256 == 0 && k_in % 256 == 0)
       return gpt_gemm_tn(dY, n_out, X, k_in, gW, k_in, n_out, k_in, M, 1, stream);
     CHECK(gpt_transpose(dt, dY, bw->tA, M, n_out, Mp, stream));
     CHECK(gpt_transpose(dt, X, bw->tB, M, k_in, Mp, stream));
@@ -358,9 +359,9 @@ extern "C" int gpt_denoiser_backward_stages(const gpt_model_t* m, const gpt_work
   // of their operands (d_qkv) exists: 432 tiles at d = 1536 = two nearly full rounds of whole contractions instead of four
   // launches of 36 ... 144 tiles.  Until then mlp.2's dY must survive the LayerNorm backward that would overwrite it: that
   // LayerNorm writes its operand copy to bw->tA (the NT fallback's transpose scratch, [4d, Mp] >= [M, d], unused on this path).
-  const bool grouped = use_tn && dt == GPT_BF16 && M % 64 == 0 && d % 256 == 0;
+  const bool grouped = use_tn && dt == GPT_BF16 && d % 256 == 0;
   GPT_REQUIRE(!bw->wgrad_overwrite || grouped,
-              "gpt_denoiser_backward: wgrad_overwrite needs the grouped TN launch (bf16, B * T %% 64 == 0, n_embd %% 256 == 0)");
+              "gpt_denoiser_backward: wgrad_overwrite needs the grouped TN launch (bf16, n_embd %% 256 == 0)");
   // Deferred weight gradients (gpt_backward_t.wgrad_defer): Block l works in slot (L - 1 - l) % G of the dY buffers and its four
   // TN problems wait in `pend` until G Blocks are collected (or the call ends): one grid for all of them.
   GPT_REQUIRE(!bw->wgrad_sumsq || bw->wgrad_overwrite, "gpt_denoiser_backward: wgrad_sumsq needs wgrad_overwrite");

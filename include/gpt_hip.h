@@ -88,7 +88,8 @@ int gpt_gemm_resadd_layernorm(int dtype, const void* A, int64_t lda, const void*
 /* C[I, J] (+)= P[R, I]^T . Q[R, J]: bf16 operands contracted over their ROW index, fp32 output (accumulate != 0:
  * C += ...).  The weight gradient dW = dY^T . X that autograd derives for every nn.Linear of the trunk
  * (Gpt/models/transformer.py:38-40, 50, 63-65), reading dY [B*T, n_out] and X [B*T, k_in] as they lie in memory
- * (transposing LDS reads, ds_read_b64_tr_b16).  I % 256 == 0, J % 256 == 0, R % 64 == 0; ldp, ldq % 8 == 0. */
+ * (transposing LDS reads, ds_read_b64_tr_b16).  I % 256 == 0, J % 256 == 0, any R > 0 (a ragged last 64-row K-tile is
+ * zero-filled); ldp, ldq % 8 == 0. */
 int gpt_gemm_tn(const void* P, int64_t ldp, const void* Q, int64_t ldq, float* C, int64_t ldc, int I, int J, int R,
                 int accumulate, void* stream);
 
@@ -349,7 +350,7 @@ typedef struct {
   float* d_tok;    /* scratch fp32 [M, d]   decoder / encoder token gradients        */
   /* != 0: the four weight gradients of every Block (g_wqkv, g_wproj, g_w1, g_w2) are STORED, not accumulated: they need no
    * zeroing before the call and are not read (no read-modify-write of 12 d^2 floats per Block).  Only valid where the grouped
-   * TN launch computes them (GPT_BF16, B * T % 64 == 0, n_embd % 256 == 0); rejected otherwise.  Every other gradient is
+   * TN launch computes them (GPT_BF16, n_embd % 256 == 0); rejected otherwise.  Every other gradient is
    * accumulated as before. */
   int wgrad_overwrite;
   /* G = 2..4: the grouped TN launches of up to G consecutive Blocks (inside one gpt_denoiser_backward_stages call) are merged

@@ -204,8 +204,9 @@ def test_cifar_big_forward_vs_oracle(dtype, bar):
 
 
 def test_cifar_big_training_step_vs_oracle():
-    """configs[4]: one bf16 training step's loss and gradients (B = 68 -> M = 1768, not a multiple of 64: the transpose + NT
-    weight-gradient route; B = 64 -> the TN / grouped route at d = 3072) against the oracle's autograd, and the fused
+    """configs[4]: one bf16 training step's loss and gradients (B = 68 -> M = 1768, not a multiple of 64: the TN / grouped
+    weight-gradient route with a zero-filled last K-tile, also on the 748 compact rows of the pruned last Block; B = 64 -> whole
+    K-tiles at d = 3072) against the oracle's autograd, and the fused
     clip + AdamW + EMA pass against torch.optim.AdamW applied to the same gradients."""
     from gpt_amd.trainstep import TrainStep
     diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)

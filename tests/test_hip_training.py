@@ -313,7 +313,7 @@ def test_layernorm_backward_partials_equal_atomics(monkeypatch, dtype, B):
 
 
 def test_store_mode_weight_gradients_equal_accumulation(monkeypatch):
-    """Where the grouped weight-gradient launch applies (bf16, B * T % 64 == 0, d % 256 == 0) TrainStep has the Blocks' weight
+    """Where the grouped weight-gradient launch applies (bf16, d % 256 == 0) TrainStep has the Blocks' weight
     gradients STORED and stops zeroing their part of the arena: three steps must give the parameters of the accumulate-into-zero
     path (a + 0 is exact; LayerNorm / bias gradients are atomically summed, hence a tolerance), and the arena really holds stale
     block-weight gradients in between."""
@@ -341,25 +341,33 @@ def test_store_mode_weight_gradients_equal_accumulation(monkeypatch):
         if k.endswith("attn.key.bias"):
             continue
         _assert_equal_up_to_adam_noise(runs[0][k], runs[1][k], k)
-    # a batch the grouped launch does not take (B * T % 64 != 0): the flag must stay off and the step must work
+    monkeypatch.setenv("GPT_WGRAD_OVERWRITE", "1")
+    # a row count that is no multiple of the TN kernel's 64-row K-tile (B * T = 130) is taken as well (zero-filled last K-tile) ...
     m, plan, sd = build("cifar_small", "bf16", seed=4)
     m.train()
     ts = TrainStep(m, diff, lr=1e-3, wd=0.1, grad_clip=0.75)
-    monkeypatch.setenv("GPT_WGRAD_OVERWRITE", "1")
     _, _, lt, lp, xp = (v.to(DEV) for v in make_inputs("cifar_small", B=5, seed=1))
+    ts.step(xp, xp + 0.1, lp, lt, torch.zeros(5, dtype=torch.long, device=DEV))
+    assert ts._overwrote and float(ts.grads[ts.arena.s_dec_start:].abs().max()) == 0.0
+    # ... a width the grouped launch does not take (n_embd = 192) is not: the flag must stay off and the step must work
+    m, plan, sd = build("mnist_small", "bf16", seed=4)
+    m.train()
+    ts = TrainStep(m, diff, lr=1e-3, wd=0.1, grad_clip=0.75)
+    _, _, lt, lp, xp = (v.to(DEV) for v in make_inputs("mnist_small", B=5, seed=1))
     ts.step(xp, xp + 0.1, lp, lt, torch.zeros(5, dtype=torch.long, device=DEV))
     assert not ts._overwrote and float(ts.grads.abs().max()) == 0.0
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype,B,store", [("bf16", 32, True), ("bf16", 5, False), ("fp32", 8, False)])
-def test_overlapped_optimizer_pass_equals_the_in_order_one(dtype, B, store):
+@pytest.mark.parametrize("dtype,B,store", [("bf16", 32, True), ("bf16", 5, True), ("bf16", 32, False), ("fp32", 8, False)])
+def test_overlapped_optimizer_pass_equals_the_in_order_one(monkeypatch, dtype, B, store):
     """overlap_update: the Blocks' share of the fused AdamW + EMA pass runs on a side stream, layer by layer, beside the next
     step's forward, which waits per block (gpt_layer_t.ready).  Four steps must give the parameters and the EMA of the in-order
     step (elementwise pass cut at layer boundaries: the only differences are those of the atomically summed gradients), read
-    through state_dict(), whose hook joins the side stream; in store mode and in accumulate mode (a batch the grouped
-    weight-gradient launch does not take; fp32)."""
+    through state_dict(), whose hook joins the side stream; in store mode (also with a ragged row count) and in accumulate mode
+    (GPT_WGRAD_OVERWRITE=0; fp32)."""
     from gpt_amd.trainstep import TrainStep
+    monkeypatch.setenv("GPT_WGRAD_OVERWRITE", "1" if store else "0")
     diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
     runs = []
     for flag in (True, False):
@@ -742,7 +750,8 @@ def test_one_rank_rccl_rehearsal_matches_single_process(tmp_path):
         assert float((prm.detach().cpu() - got[k]).abs().max()) < 5e-5 * max(1.0, float(got[k].abs().max())), k
 
 
-@pytest.mark.parametrize("I,J,R", [(256, 256, 64), (512, 768, 832), (1536, 256, 3328), (256, 512, 8256)])   # last: 16 row spans, ragged
+@pytest.mark.parametrize("I,J,R", [(256, 256, 64), (512, 768, 832), (1536, 256, 3328), (256, 512, 8256),     # 8256: 16 row spans, ragged
+                                   (256, 256, 40), (512, 256, 130), (768, 512, 1768), (256, 512, 8243)])     # R % 64 != 0: zero-filled last K-tile
 @pytest.mark.parametrize("accumulate", [0, 1])
 def test_gemm_tn_matches_torch(I, J, R, accumulate):
     """C (+)= P^T Q with both bf16 operands read as stored (transposing LDS reads) against an fp64 product."""
@@ -754,8 +763,14 @@ def test_gemm_tn_matches_torch(I, J, R, accumulate):
     L.check(L.lib().gpt_gemm_tn(L.ptr(P), I, L.ptr(Q), J, L.ptr(C), J, I, J, R, accumulate, L.stream()), "gpt_gemm_tn")
     ref = P.double().t() @ Q.double() + (C0.double() if accumulate else 0)
     assert float((C.double() - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+    # a shorter contraction over the same buffers (any R is accepted: the last K-tile is zero-filled past it)
+    if R > 32:
+        L.check(L.lib().gpt_gemm_tn(L.ptr(P), I, L.ptr(Q), J, L.ptr(C), J, I, J, R - 29, 0, L.stream()), "gpt_gemm_tn")
+        ref = P[:R - 29].double().t() @ Q[:R - 29].double()
+        assert float((C.double() - ref).abs().max()) < 2e-3 * float(ref.abs().max())
     # rejected shapes: no launch
-    assert L.lib().gpt_gemm_tn(L.ptr(P), I, L.ptr(Q), J, L.ptr(C), J, I, J, R - 32, 0, L.stream()) != 0
+    assert L.lib().gpt_gemm_tn(L.ptr(P), I, L.ptr(Q), J, L.ptr(C), J, I - 8, J, R, 0, L.stream()) != 0
+    assert L.lib().gpt_gemm_tn(L.ptr(P), I, L.ptr(Q), J, L.ptr(C), J, I, J, 0, 0, L.stream()) != 0
 
 
 @pytest.mark.parametrize("R", [832, 3328])
@@ -789,8 +804,10 @@ def test_gemm_tn_grouped_matches_single_launches(R):
                                        i32(d, 4 * d, 3 * d, d + 8), i32(*[j for _, j in shapes]), R, 1, L.stream()) != 0
 
 
-def test_wgrad_tn_path_equals_transpose_path():
-    """The weight gradients through the TN kernel (cifar_small: d = 256, B*T % 64 == 0) equal the transpose + NT route."""
+@pytest.mark.parametrize("B", [32, 5, 37])
+def test_wgrad_tn_path_equals_transpose_path(B):
+    """The weight gradients through the TN kernel (cifar_small: d = 256; B = 5 / 37: B * T = 130 / 962 rows, ragged last K-tile of
+    the contraction, and so for the compact rows of the pruned last Block) equal the transpose + NT route on all rows."""
     import os
     import subprocess
     import sys
@@ -803,10 +820,11 @@ import gpt_amd
 m, plan, sd = build("cifar_small", "bf16", seed=6)
 m.train()
 diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
-_, _, lt, lp, xp = (v.to(DEV) for v in make_inputs("cifar_small", B=32, seed=7))
+B = int(sys.argv[2])
+_, _, lt, lp, xp = (v.to(DEV) for v in make_inputs("cifar_small", B=B, seed=7))
 g = torch.Generator().manual_seed(8)
 x1 = xp + 0.1 * torch.randn(xp.shape, generator=g).to(DEV)
-t = torch.randint(0, 1000, (32,), generator=g).to(DEV)
+t = torch.randint(0, 1000, (B,), generator=g).to(DEV)
 noise = torch.randn(xp.shape, generator=g).to(DEV)
 diff.training_losses(m, x1, t, model_kwargs=dict(loss_target=lt, loss_prev=lp, x_prev=xp), noise=noise)["loss"].mean().backward()
 torch.save({k: p.grad.cpu() for k, p in m.named_parameters()}, sys.argv[1])
@@ -817,11 +835,17 @@ torch.save({k: p.grad.cpu() for k, p in m.named_parameters()}, sys.argv[1])
         for flag in ("1", "0"):
             path = os.path.join(td, f"g{flag}.pt")
             env = dict(os.environ, GPT_WGRAD_TN=flag)
-            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=200)
+            subprocess.run([sys.executable, "-c", code, path, str(B)], check=True, env=env, timeout=200)
             outs.append(torch.load(path, weights_only=True))
+    # (the TN route also prunes the last Block to the decoded rows, whose GEMMs take other kernel instances: equal to bf16 rounding
+    # of the activations there, to fp32 summation order elsewhere)
     for k in outs[0]:
-        a, b = outs[0][k], outs[1][k]
-        assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-12) + 1e-9, k
+        a, b = outs[0][k].double(), outs[1][k].double()
+        if k.endswith("attn.key.bias"):
+            continue
+        err = float((a - b).abs().max() / (b.abs().max() + 1e-30))
+        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+        assert err < 1.5e-2 and cos > 0.9999, (k, err, cos)
 
 
 def test_pruned_last_block_training_equals_all_rows():
@@ -841,7 +865,7 @@ from tests.cases import make_inputs
 import gpt_amd
 from gpt_amd.trainstep import TrainStep
 out = {}
-for tag, B in (("store", 64), ("accum", 128)):
+for tag, B in (("store", 64), ("accum", 128), ("store_ragged", 37)):      # 37 * 26 = 962 rows, 37 * 11 = 407 compact: no multiple of 64
     m, plan, sd = build("cifar_small", "bf16", seed=6)
     m.train()
     diff = gpt_amd.create_diffusion(learn_sigma=False, predict_xstart=True, noise_schedule="linear", steps=1000)
@@ -850,7 +874,7 @@ for tag, B in (("store", 64), ("accum", 128)):
     x1 = xp + 0.1 * torch.randn(xp.shape, generator=g).to(DEV)
     t = torch.randint(0, 1000, (B,), generator=g).to(DEV)
     noise = torch.randn(xp.shape, generator=g).to(DEV)
-    if tag == "store":
+    if tag.startswith("store"):
         ts = TrainStep(m, diff, lr=1e-3, wd=0.1, grad_clip=0.75, use_ema=False)
         out[tag + ".mse"] = ts.loss_and_grads(xp, x1, lp, lt, t, noise=noise).cpu()
         assert ts._overwrote
