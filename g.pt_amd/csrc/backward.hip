@@ -34,16 +34,21 @@ __device__ __forceinline__ void store_row4(bf16_t* p, f32x4 v) {
   *reinterpret_cast<uint2*>(p) = u;
 }
 
-constexpr int LNB_WAVES = 8;   // waves per workgroup: few workgroups (the dgamma / dbeta flush is one fp32 atomic per column per
-                               // workgroup, and atomics are slow) but enough waves per CU to hide the row loads
+// LNB_WAVES waves per workgroup: few workgroups (the dgamma / dbeta flush is one fp32 atomic per column per workgroup, and atomics
+// are slow) but enough waves per CU to hide the row loads.  8 of them have 256 registers per lane each: at NCH = 12 (n_embd 3072) the
+// row and its three accumulator sets need about 400, and the 8-wave build spilled 293 registers to scratch (86.7 us per launch at
+// M = 1768, 0.8 TB/s); that width runs 4 waves per workgroup, one per SIMD, 512 registers each.
+template <int NCH>
+constexpr int lnb_waves = NCH > 8 ? 4 : 8;
 template <typename DyT, typename OutT, int NCH>
-__global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const DyT* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(lnb_waves<NCH> * 64) void layernorm_bwd_kernel(const DyT* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ resid,
                                                             float* __restrict__ gout, OutT* __restrict__ gout_t,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             float* __restrict__ gcol, float* __restrict__ part, int rows, int d,
                                                             int rows_per_block) {
+  constexpr int LNB_WAVES = lnb_waves<NCH>;
   extern __shared__ __attribute__((aligned(16))) float red[];  // [LNB_WAVES][d]: the waves' partial dgamma, then dbeta, then gcol
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // gcol (optional): column sums of gout = the bias gradient of the Linear whose output gradient gout is (the launch is at most
@@ -821,12 +826,13 @@ int gpt_layernorm_bwd_part(const void* dy, int dy_dtype, const float* x, const f
   GPT_REQUIRE(dy && x && mean && rstd && gamma && gout && dgamma && dbeta, "gpt_layernorm_bwd: null operand");
   GPT_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 3072, "gpt_layernorm_bwd: bad sizes (need d %% 4 == 0, d <= 3072)");
   // every workgroup ends with one atomic per column on the SAME 2d addresses: their number, not the streaming, sets the tail
-  int blocks = (rows + LNB_WAVES - 1) / LNB_WAVES;
+  const int waves = d > 2048 ? lnb_waves<12> : lnb_waves<8>;  // as the instance chosen below
+  int blocks = (rows + waves - 1) / waves;
   blocks = blocks > 256 ? 256 : blocks;
   const int rpb = (rows + blocks - 1) / blocks;
-  const dim3 grid((rows + rpb - 1) / rpb), block(LNB_WAVES * 64);
+  const dim3 grid((rows + rpb - 1) / rpb), block(waves * 64);
   if (n_blocks) *n_blocks = (int)grid.x;                      // rows of the partials buffer this launch fills (<= 256)
-  const size_t lds = (size_t)LNB_WAVES * d * sizeof(float);   // <= 96 KiB at d = 3072
+  const size_t lds = (size_t)waves * d * sizeof(float);       // <= 64 KiB
   hipStream_t s = (hipStream_t)stream;
   const bool dyb = dy_dtype == GPT_BF16, ob = gout_t_dtype == GPT_BF16;
 #define LNB(DY, OUT, NCH)                                                                                              \
@@ -835,7 +841,7 @@ int gpt_layernorm_bwd_part(const void* dy, int dy_dtype, const float* x, const f
     bool& attr_set = attr.here();                                                                                       \
     if (!attr_set) {                                                                                                    \
       if (hipFuncSetAttribute((const void*)layernorm_bwd_kernel<DY, OUT, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              LNB_WAVES * NCH * 256 * (int)sizeof(float)) != hipSuccess) {                              \
+                              lnb_waves<NCH> * NCH * 256 * (int)sizeof(float)) != hipSuccess) {                              \
         gpt_set_error("gpt_layernorm_bwd: cannot reserve LDS");                                                         \
         return -1;                                                                                                      \
       }                                                                                                                 \
