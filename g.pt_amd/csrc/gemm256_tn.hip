@@ -58,7 +58,9 @@ struct TnGroup {
   float* sumsq;   // store mode: += sum of squares of every stored tile (one float atomic per wave), or NULL
 };
 
-template <int EPI>
+// RAGGED: some problem of the group has a contraction length that is no multiple of 64 (the branch below, although taken by one
+// K-tile per workgroup at most, costs the steady loop 2.5 - 4 % when compiled in: whole-tile launches get the instance without it)
+template <int EPI, bool RAGGED>
 __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(TnGroup grp) {
   using T = bf16_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -91,29 +93,36 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(TnGroup grp) {
   // lane -> (row = lane >> 4, chunk = lane & 15) of the piece, the chunk's logical position un-swizzled
   const T* srcP[2][2];  // [half][piece]
   const T* srcQ[2][2];
-  const T* endQ[2][2];  // the same columns of row R - 1: what a Q row past the end reads instead (its P partner is zero)
-  const T* endP[2][2];  // zeros
-  int left[2];          // rows of this span from the piece's row of K-tile 0 to the end of the contraction (<= 0: none)
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     const int lr = wid * 8 + p * 4 + (lane >> 4);
     const int lc = (lane & 15) ^ ((lr & 3) << 2) ^ (((lr >> 3) & 1) << 1);   // logical 16-byte chunk (8 columns) of the 128-column row
     const int e = lc * 8;
-    left[p] = g.K - (kt0 * 64 + lr);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       srcP[h][p] = g.A + ((int64_t)kt0 * 64 + lr) * g.lda + m0 + h * 128 + e;
       srcQ[h][p] = g.W + ((int64_t)kt0 * 64 + lr) * g.ldw + n0 + h * 128 + e;
-      endQ[h][p] = g.W + ((int64_t)g.K - 1) * g.ldw + n0 + h * 128 + e;
-      endP[h][p] = reinterpret_cast<const T*>(g_zero16);
     }
   }
   const int64_t stepP = 64 * g.lda, stepQ = 64 * g.ldw;
-  // (only the last K-tile of a ragged contraction ever takes `end`: two selects per instruction otherwise)
-  auto dma = [&](const T* const (&src)[2], const T* const (&end)[2], int64_t step, int kt, int slot) {
+  // A ragged contraction (R % 64 != 0) ends in a K-tile with rows past R: P reads zeros for them, Q its last valid row (finite
+  // values times zero).  Only that one K-tile of the last span takes the branch (workgroup-uniform), everything else the two plain
+  // instructions: the selects cost the steady loop nothing.
+  const int full_tiles = g.K / 64 - kt0;                     // K-tiles of this span, counted from its first, that are whole
+  auto dma = [&](const T* const (&src)[2], int64_t step, int kt, int slot, bool is_q) {
     char* dst = smem + (kt & 1) * TBUF + slot * THALF + wid * 2048;
-    const T* s0 = kt * 64 < left[0] ? src[0] + kt * step : end[0];
-    const T* s1 = kt * 64 < left[1] ? src[1] + kt * step : end[1];
+    const T* s0 = src[0] + kt * step;
+    const T* s1 = src[1] + kt * step;
+    if (RAGGED && kt >= full_tiles) {
+      const int over0 = (kt0 + kt) * 64 + wid * 8 + (lane >> 4) - (g.K - 1), over1 = over0 + 4;   // rows past the last valid one
+      if (is_q) {
+        if (over0 > 0) s0 -= (int64_t)over0 * g.ldw;
+        if (over1 > 0) s1 -= (int64_t)over1 * g.ldw;
+      } else {
+        if (over0 > 0) s0 = reinterpret_cast<const T*>(g_zero16);
+        if (over1 > 0) s1 = reinterpret_cast<const T*>(g_zero16);
+      }
+    }
     __builtin_amdgcn_global_load_lds((gptr_t)s0, (lptr_t)dst, 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gptr_t)s1, (lptr_t)(dst + 1024), 16, 0, 0);
   };
@@ -128,10 +137,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(TnGroup grp) {
 #pragma unroll
   for (int t = 0; t < 2; ++t)
     if (t < nk) {
-      dma(srcP[0], endP[0], stepP, t, 0);
-      dma(srcQ[0], endQ[0], stepQ, t, 2);
-      dma(srcQ[1], endQ[1], stepQ, t, 3);
-      dma(srcP[1], endP[1], stepP, t, 1);
+      dma(srcP[0], stepP, t, 0, false);
+      dma(srcQ[0], stepQ, t, 2, true);
+      dma(srcQ[1], stepQ, t, 3, true);
+      dma(srcP[1], stepP, t, 1, false);
     }
 
   // transposed-read addresses: 16-lane group gq reads the block rows 8 gq + q (then + 4), columns e0 + 4 p .. + 3
@@ -195,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(TnGroup grp) {
     read_q(b0, buf + 2 * THALF);
     read_p(a, buf);
     read_q(b1, buf + 3 * THALF);
-    if (kt >= 1 && !last) dma(srcP[1], endP[1], stepP, kt + 1, 1);
+    if (kt >= 1 && !last) dma(srcP[1], stepP, kt + 1, 1, false);
     SEG_READS_DONE();
     SEG_BARRIER();
     __builtin_amdgcn_s_setprio(1);
@@ -208,9 +217,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(TnGroup grp) {
     SEG_BARRIER();
     read_p(a, buf + THALF);
     if (steady) {
-      dma(srcP[0], endP[0], stepP, kt + 2, 0);
-      dma(srcQ[0], endQ[0], stepQ, kt + 2, 2);
-      dma(srcQ[1], endQ[1], stepQ, kt + 2, 3);
+      dma(srcP[0], stepP, kt + 2, 0, false);
+      dma(srcQ[0], stepQ, kt + 2, 2, true);
+      dma(srcQ[1], stepQ, kt + 2, 3, true);
     }
     SEG_READS_DONE();
     SEG_BARRIER();
@@ -284,12 +293,12 @@ int pick_tn_spans(int tiles, int nk_all) {
   return ksplit;
 }
 
-template <int EPI>
+template <int EPI, bool RAGGED>
 int launch_tn(TnGroup& grp, hipStream_t s) {
   static GptPerDevice attr;   // the LDS grant is per kernel AND per device (a process may drive several GPUs)
   bool& attr_set = attr.here();
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm256_tn_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, TLDS_BYTES) !=
+    if (hipFuncSetAttribute((const void*)gemm256_tn_kernel<EPI, RAGGED>, hipFuncAttributeMaxDynamicSharedMemorySize, TLDS_BYTES) !=
         hipSuccess) {
       gpt_set_error("gpt_gemm_tn: cannot reserve %d bytes of LDS", TLDS_BYTES);
       return -1;
@@ -307,7 +316,7 @@ int launch_tn(TnGroup& grp, hipStream_t s) {
   for (int p = 0; p < grp.n; ++p) grp.off[p + 1] = grp.off[p] + (grp.g[p].M / 256) * (grp.g[p].N / 256) * grp.ksplit;
   const bool rec = g_prof.on && g_prof.n < GemmProf::CAP;
   if (rec) (void)hipEventRecord(g_prof.ev[g_prof.n][0], s);
-  hipLaunchKernelGGL((gemm256_tn_kernel<EPI>), dim3(grp.off[grp.n]), dim3(512), TLDS_BYTES, s, grp);
+  hipLaunchKernelGGL((gemm256_tn_kernel<EPI, RAGGED>), dim3(grp.off[grp.n]), dim3(512), TLDS_BYTES, s, grp);
   if (rec) {
     (void)hipEventRecord(g_prof.ev[g_prof.n][1], s);
     g_prof.flops[g_prof.n++] = flops;
@@ -360,5 +369,9 @@ int gpt_tn_grouped_sumsq_r(int n, const void* const* P, const int64_t* ldp, cons
   }
   // (an accumulating launch may cut the contractions into spans: ONE span count for the group, chosen for the first problem; every
   // problem cuts its own length by it and the kernel drops the spans a shorter problem leaves empty)
-  return accumulate ? launch_tn<GPT_EPI_ACCUM_F32>(grp, (hipStream_t)stream) : launch_tn<GPT_EPI_STORE_F32>(grp, (hipStream_t)stream);
+  bool ragged = false;
+  for (int p = 0; p < n; ++p) ragged = ragged || R[p] % 64 != 0;
+  hipStream_t hs = (hipStream_t)stream;
+  if (ragged) return accumulate ? launch_tn<GPT_EPI_ACCUM_F32, true>(grp, hs) : launch_tn<GPT_EPI_STORE_F32, true>(grp, hs);
+  return accumulate ? launch_tn<GPT_EPI_ACCUM_F32, false>(grp, hs) : launch_tn<GPT_EPI_STORE_F32, false>(grp, hs);
 }
