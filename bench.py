@@ -41,8 +41,13 @@ PEAK = {"bf16": 2500.0, "fp32": 157.3}          # dense MFMA TFLOP/s, /opt/skill
 def flops_per_forward(case):
     """Algorithmic FLOPs per sample per denoiser forward."""
     c = CASES[case]
-    d, Lr, T, D = c["n_embd"], c["n_layer"], 26, sum(c["parameter_sizes"])   # T: both real token plans have 26 tokens
+    d, Lr, T, D = c["n_embd"], c["n_layer"], n_tokens(case), sum(c["parameter_sizes"])
     return 2 * T * Lr * 12 * d * d + 4 * Lr * T * T * d + 2 * d * (2 * D + 4 * 257) + 2 * d * D
+
+
+def n_tokens(case):
+    """26 tokens for the MNIST / CIFAR-10 plans (chunk_within_layer), 18 for Cartpole's (layer_by_layer: 7 + 7 tensors + 4 scalars)."""
+    return 18 if case.startswith("cartpole") else 26
 
 
 def make_model(case, dtype, device, seed=0):
@@ -256,7 +261,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--mode", default="sample", choices=["sample", "train"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--case", default="mnist", choices=["mnist", "cifar", "cifar_big"])
+    ap.add_argument("--case", default="mnist", choices=["mnist", "cifar", "cifar_big", "cartpole"])
     ap.add_argument("--data", default="synthetic", choices=["synthetic", "store"],
                     help="--mode train: 'store' draws every batch from an HBM-resident checkpoint store (g.pt_amd/data.py)")
     ap.add_argument("--augment", action="store_true",
@@ -512,7 +517,7 @@ def bench_sample(args, device, world, rank, cpu=True):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{'mnist_loss' if case == 'mnist' else 'cifar10_error' if case == 'cifar' else case} G.pt shapes "
-                               f"(D={D}, n_embd={CASES[case]['n_embd']}, {CASES[case]['n_layer']} layers, 26 tokens), "
+                               f"(D={D}, n_embd={CASES[case]['n_embd']}, {CASES[case]['n_layer']} layers, {n_tokens(case)} tokens), "
                                f"1000-step DDPM p_sample_loop, B={B} vectors per GPU, random-init weights, "
                                f"in-kernel Philox noise; step = 1 reverse-diffusion step",
                    "batch_per_gpu": B, "diffusion_steps": diff.num_timesteps},

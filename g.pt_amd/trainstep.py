@@ -493,8 +493,10 @@ def bench_train(args, device, world, rank):
     sampler = gpt_amd.UniformSampler(diff)
     np.random.seed(world + rank)               # Gpt/utils.py:73-75 with rng_seed = 1
     mnist = case.startswith("mnist")
-    clip = 0.75 if mnist else 0.1              # configs/train/mnist_loss.yaml / cifar10_error.yaml: train.grad_clip
-    cfg_name = "configs/train/mnist_loss.yaml" if mnist else "configs/train/cifar10_error.yaml"
+    # train.grad_clip of configs/train/mnist_loss.yaml / cartpole.yaml (no clipping) / cifar10_error.yaml
+    clip = 0.75 if mnist else 0.0 if case.startswith("cartpole") else 0.1
+    cfg_name = ("configs/train/mnist_loss.yaml" if mnist else "configs/train/cartpole.yaml" if case.startswith("cartpole")
+                else "configs/train/cifar10_error.yaml")
     if case == "cifar_big":
         c = CASES[case]
         cfg_name += f" with a scaled-up transformer (n_embd {c['n_embd']}, {c['n_head']} heads, {c['n_layer']} layers)"
@@ -507,7 +509,8 @@ def bench_train(args, device, world, rank):
     augment = getattr(args, "augment", False)
     if augment:
         from . import permute
-        arch = permute.MLP_ARCH if case.startswith("mnist") else permute.CNN_ARCH
+        arch = (permute.MLP_ARCH if case.startswith("mnist") else permute.ACTOR_ARCH if case.startswith("cartpole")
+                else permute.CNN_ARCH)
 
     store = None
     if getattr(args, "data", "synthetic") == "store":
