@@ -54,7 +54,8 @@ def _compare_grads(got, ref, max_bar, cos_bar):
 @pytest.mark.parametrize("dtype,B,max_bar,cos_bar", [
     ("fp32", 32, 1e-3, 0.999999),      # M = 832 rows
     ("bf16", 32, 3e-2, 0.999),         # M % 64 == 0: TN + grouped weight-gradient launch, K-span dgrad
-    ("bf16", 128, 3e-2, 0.999)])       # the 8-GPU per-GPU batch bench.py times as `train_weak` (M = 3328: 224-row tiles on fc1)
+    ("bf16", 128, 3e-2, 0.999),        # the 8-GPU per-GPU batch bench.py times as `train_weak` (M = 3328: 224-row tiles on fc1)
+    ("bf16", 5, 3e-2, 0.999)])         # M = 130, 55 compact rows: ragged contraction lengths in the grouped weight-gradient launch
 def test_full_size_training_gradients_vs_oracle(dtype, B, max_bar, cos_bar):
     """configs[3] at the pretrained mnist shapes (d = 1536, 12 layers, 16 heads): training_losses + backward through the HIP
     path (TrainStep.loss_and_grads: q_sample, kept-activation forward, row MSE, staged backward into the flat gradient arena)
