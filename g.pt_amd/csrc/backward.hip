@@ -651,8 +651,11 @@ __device__ __forceinline__ void cols_product_store(const T* __restrict__ src, in
   }
 }
 
+// Two workgroups per CU asked of the register allocator for head dims <= 96: 182 registers and no AGPR copies instead of 168 + 48
+// (same two waves per SIMD): 195 -> 182 us at B = 1024, 29.7 -> 28.4 at B = 128; head dim 128 measures 4 % slower that way and
+// three workgroups per CU (8 spilled registers) slower everywhere (tools/attn_bench.py, A/B x2 on one box).
 template <typename T, int HD>
-__global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dy,
+__global__ __launch_bounds__(256, HD <= 96 ? 2 : 1) void attention_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dy,
                                                             T* __restrict__ dqkv, int B, int Ttok, int n_head) {
   const int lane = threadIdx.x & 63;
   const int r = lane & 31, hh = lane >> 5;

@@ -26,5 +26,20 @@ for B, H, hd in cases:
         if i >= 0:
             ts.append(e0.elapsed_time(e1) * 1e3)
     ts.sort()
+    dy = torch.randn(B * T, d, device=dev).bfloat16()
+    dq = torch.empty(B * T, 3 * d, device=dev, dtype=torch.bfloat16)
+    tb = []
+    for i in range(-5, 30):
+        q, y = sets[i % 4]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(lib.gpt_attention_bwd(L.BF16, L.ptr(q), L.ptr(dy), L.ptr(dq), B, T, H, hd, L.stream()), "gpt_attention_bwd")
+        e1.record()
+        torch.cuda.synchronize()
+        if i >= 0:
+            tb.append(e0.elapsed_time(e1) * 1e3)
+    tb.sort()
+    mbb = B * T * 7 * d * 2 / 1e6
+    print(f"   backward: median {tb[len(tb) // 2]:7.1f} us  min {tb[0]:7.1f} us  {mbb:7.1f} MB  {mbb / tb[len(tb) // 2]:6.2f} TB/s")
     mb = B * T * 4 * d * 2 / 1e6
     print(f"B={B:5d} H={H:3d} hd={hd:4d}: median {ts[len(ts) // 2]:7.1f} us  min {ts[0]:7.1f} us  {mb:7.1f} MB  {mb / ts[len(ts) // 2] * 1e-3 * 1e3:6.2f} TB/s", flush=True)
